@@ -1,0 +1,117 @@
+"""dwt_amd — host-side mirror of the xdsopl/dwt encode/decode hot path on MI355X.
+
+Everything here is plumbing over the C ABI in include/dwtx.h (libdwtx.so,
+hand-written HIP for gfx950): torch supplies device memory and streams, the
+library does the work.  Function names follow the reference's
+(`transformation`, `linearization`, `reconstruction`, ... in encode.c/decode.c).
+There is no CPU fallback: without the built library or without a GPU the calls
+raise.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import Geom, Stats, LIB_PATH  # noqa: F401
+
+__all__ = ["Context", "DwtxError", "compute_lengths", "geometry", "Geom", "Stats"]
+
+
+class DwtxError(RuntimeError):
+    def __init__(self, rc, what):
+        msg = _lib.load().dwtx_last_error().decode(errors="replace")
+        super().__init__(f"{what} failed with {rc}: {msg}")
+        self.rc = rc
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DwtxError(rc, what)
+
+
+def compute_lengths(W, H, N0=8):
+    """utils.h:28 compute_lengths -> (levels, lengths, pixels, widths, heights)."""
+    lib = _lib.load()
+    arr = [(C.c_int * 16)() for _ in range(4)]
+    levels = lib.dwtx_compute_lengths(arr[0], arr[1], arr[2], arr[3], W, H, N0)
+    return (levels,) + tuple(list(a[: levels + 1]) for a in arr)
+
+
+def geometry(W, H):
+    g = Geom()
+    _check(_lib.load().dwtx_geometry(C.byref(g), W, H), "dwtx_geometry")
+    return g
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One HIP device + stream + scratch arena (dwtx_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+
+        self.torch = torch
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("dwt_amd needs a HIP device; there is no CPU path")
+        self.device = torch.device("cuda", device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _check(self.lib.dwtx_ctx_create(device, C.c_void_p(stream), C.byref(h)), "dwtx_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dwtx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self.lib.dwtx_sync(self.h), "dwtx_sync")
+
+    # -- stage kernels -------------------------------------------------------
+
+    def planes_from_pixels(self, pix):
+        """uint8 [n,H,W,C] interleaved -> int32 [n*C,H,W] planar (YCoCg-R if C==3)."""
+        torch = self.torch
+        n, H, W, Cn = pix.shape
+        assert pix.dtype == torch.uint8 and pix.is_contiguous() and pix.device == self.device
+        out = torch.empty((n * Cn, H, W), dtype=torch.int32, device=self.device)
+        _check(self.lib.dwtx_planes_from_pixels(self.h, _ptr(out), _ptr(pix), W, H, Cn, n), "dwtx_planes_from_pixels")
+        return out
+
+    def pixels_from_planes(self, planes, C_):
+        torch = self.torch
+        nC, H, W = planes.shape
+        n = nC // C_
+        assert planes.dtype == torch.int32 and planes.is_contiguous()
+        out = torch.empty((n, H, W, C_), dtype=torch.uint8, device=self.device)
+        _check(self.lib.dwtx_pixels_from_planes(self.h, _ptr(out), _ptr(planes), W, H, C_, n), "dwtx_pixels_from_planes")
+        return out
+
+    def transformation_fwd(self, planes, out=None):
+        """encode.c:16 transformation: int32 [P,H,W] -> Mallat pyramid [P,H,W]."""
+        torch = self.torch
+        P, H, W = planes.shape
+        assert planes.dtype == torch.int32 and planes.is_contiguous()
+        if out is None:
+            out = torch.empty_like(planes)
+        _check(self.lib.dwtx_transformation_fwd(self.h, _ptr(out), _ptr(planes), W, H, P), "dwtx_transformation_fwd")
+        return out
+
+    def transformation_inv(self, pyr, out=None):
+        """decode.c:16 transformation (inverse)."""
+        torch = self.torch
+        P, H, W = pyr.shape
+        assert pyr.dtype == torch.int32 and pyr.is_contiguous()
+        if out is None:
+            out = torch.empty_like(pyr)
+        _check(self.lib.dwtx_transformation_inv(self.h, _ptr(out), _ptr(pyr), W, H, P), "dwtx_transformation_inv")
+        return out

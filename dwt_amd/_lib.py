@@ -1,0 +1,74 @@
+"""ctypes loader for libdwtx.so (the C ABI declared in include/dwtx.h).
+
+The library is hand-written HIP for gfx950; there is no CPU or PyTorch
+fallback.  If the shared object is missing this module raises at import of the
+symbol table, and every compute entry point fails loudly without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdwtx.so")
+
+MAX_LEVELS = 16
+
+
+class Geom(C.Structure):
+    _fields_ = [
+        ("levels", C.c_int),
+        ("widths", C.c_int * MAX_LEVELS),
+        ("heights", C.c_int * MAX_LEVELS),
+        ("pixels", C.c_int * MAX_LEVELS),
+        ("lengths", C.c_int * MAX_LEVELS),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("meta_bits", C.c_int),
+        ("root_bits", C.c_int),
+        ("total_bits", C.c_int),
+        ("kib", C.c_int),
+        ("levels", C.c_int),
+        ("planes", C.c_int * 3),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/dwtx.h declares
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "dwtx_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "dwtx_ctx_destroy": (None, [_vp]),
+    "dwtx_last_error": (C.c_char_p, []),
+    "dwtx_sync": (_i, [_vp]),
+    "dwtx_stream": (_vp, [_vp]),
+    "dwtx_malloc": (_vp, [_vp, _sz]),
+    "dwtx_free": (None, [_vp, _vp]),
+    "dwtx_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "dwtx_download": (_i, [_vp, _vp, _vp, _sz]),
+    "dwtx_compute_lengths": (_i, [C.POINTER(_i)] * 4 + [_i, _i, _i]),
+    "dwtx_geometry": (_i, [C.POINTER(Geom), _i, _i]),
+    "dwtx_planes_from_pixels": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dwtx_pixels_from_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dwtx_transformation_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdwtx.so once and type its symbols.  Raises OSError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(
+                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dwt_amd/csrc` (there is no fallback path)")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

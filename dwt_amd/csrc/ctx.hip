@@ -1,0 +1,178 @@
+// ctx.hip — context, device memory helpers, host-side geometry.
+#include "dwtx_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void dwtx_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char *dwtx_last_error(void)
+{
+	return g_err;
+}
+
+extern "C" int dwtx_ctx_create(int device, void *stream, dwtx_ctx **out)
+{
+	if (!out)
+		return DWTX_ERR_ARG;
+	int count = 0;
+	DWTX_HIP(hipGetDeviceCount(&count));
+	if (device < 0 || device >= count) {
+		dwtx_set_error("device %d out of range (%d visible)", device, count);
+		return DWTX_ERR_ARG;
+	}
+	DWTX_HIP(hipSetDevice(device));
+	dwtx_ctx *c = (dwtx_ctx *)calloc(1, sizeof(dwtx_ctx));
+	if (!c)
+		return DWTX_ERR_NOMEM;
+	c->device = device;
+	if (stream) {
+		c->stream = (hipStream_t)stream;
+		c->own_stream = false;
+	} else {
+		hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			free(c);
+			dwtx_set_error("hipStreamCreate -> %s", hipGetErrorString(e));
+			return DWTX_ERR_DEVICE;
+		}
+		c->own_stream = true;
+	}
+	*out = c;
+	return DWTX_OK;
+}
+
+extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
+{
+	if (!c)
+		return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (int i = 0; i < DWTX_SCRATCH_SLOTS; ++i)
+		if (c->scratch[i])
+			(void)hipFree(c->scratch[i]);
+	if (c->own_stream)
+		(void)hipStreamDestroy(c->stream);
+	free(c);
+}
+
+extern "C" int dwtx_sync(dwtx_ctx *c)
+{
+	DWTX_HIP(hipStreamSynchronize(c->stream));
+	return DWTX_OK;
+}
+
+extern "C" void *dwtx_stream(dwtx_ctx *c)
+{
+	return (void *)c->stream;
+}
+
+extern "C" void *dwtx_malloc(dwtx_ctx *c, size_t bytes)
+{
+	void *p = nullptr;
+	(void)hipSetDevice(c->device);
+	hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+	if (e != hipSuccess) {
+		dwtx_set_error("hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void dwtx_free(dwtx_ctx *c, void *dev)
+{
+	if (!dev)
+		return;
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(dev);
+}
+
+extern "C" int dwtx_upload(dwtx_ctx *c, void *dev, const void *host, size_t bytes)
+{
+	DWTX_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+	DWTX_HIP(hipStreamSynchronize(c->stream));
+	return DWTX_OK;
+}
+
+extern "C" int dwtx_download(dwtx_ctx *c, void *host, const void *dev, size_t bytes)
+{
+	DWTX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+	DWTX_HIP(hipStreamSynchronize(c->stream));
+	return DWTX_OK;
+}
+
+void *dwtx_scratch(dwtx_ctx *c, int slot, size_t bytes)
+{
+	if (slot < 0 || slot >= DWTX_SCRATCH_SLOTS)
+		return nullptr;
+	if (c->scratch_bytes[slot] >= bytes && c->scratch[slot])
+		return c->scratch[slot];
+	// kernels still in flight may use the old buffer
+	(void)hipStreamSynchronize(c->stream);
+	if (c->scratch[slot])
+		(void)hipFree(c->scratch[slot]);
+	c->scratch[slot] = nullptr;
+	c->scratch_bytes[slot] = 0;
+	size_t want = bytes + bytes / 8 + 256;
+	void *p = nullptr;
+	if (hipMalloc(&p, want) != hipSuccess) {
+		dwtx_set_error("scratch hipMalloc(%zu) failed", want);
+		return nullptr;
+	}
+	c->scratch[slot] = p;
+	c->scratch_bytes[slot] = want;
+	return p;
+}
+
+// ---- geometry (utils.h:9-40) ------------------------------------------------
+
+static int floor_log2(int v)
+{
+	int l = -1;
+	for (; v > 0; v >>= 1)
+		++l;
+	return l;
+}
+
+extern "C" int dwtx_compute_lengths(int *lengths, int *pixels, int *widths, int *heights, int W, int H, int N0)
+{
+	// sizes from fine to coarse: halve (round up) once, then again while the
+	// halves are still >= N0 (utils.h:17-26)
+	int ws[DWTX_MAX_LEVELS + 1], hs[DWTX_MAX_LEVELS + 1];
+	int n = 0;
+	ws[0] = W;
+	hs[0] = H;
+	do {
+		ws[n + 1] = (ws[n] + 1) >> 1;
+		hs[n + 1] = (hs[n] + 1) >> 1;
+		++n;
+	} while (n < DWTX_MAX_LEVELS - 1 && ws[n] >= N0 && hs[n] >= N0);
+	for (int l = 0; l <= n; ++l) {
+		int w = ws[n - l], h = hs[n - l];
+		widths[l] = w;
+		heights[l] = h;
+		pixels[l] = w * h;
+		int a = 1 << (floor_log2(w - 1) + 1);
+		int b = 1 << (floor_log2(h - 1) + 1);
+		lengths[l] = a > b ? a : b;
+	}
+	return n;
+}
+
+extern "C" int dwtx_geometry(dwtx_geom *g, int W, int H)
+{
+	if (!g || W < 1 || H < 1)
+		return DWTX_ERR_ARG;
+	g->levels = dwtx_compute_lengths(g->lengths, g->pixels, g->widths, g->heights, W, H, DWTX_MIN_LEN);
+	return DWTX_OK;
+}

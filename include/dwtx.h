@@ -1,0 +1,103 @@
+/*
+ * dwtx.h — C ABI of the MI355X-native encode/decode hot path of xdsopl/dwt.
+ *
+ * The reference (/root/reference) has no FFI layer: its hot path is a set of
+ * header-defined C functions called from two main()s.  This header declares the
+ * entry points a maintainer would bind in their place; each cites the
+ * reference call site / function it replaces.  Plain C types only: device and
+ * host buffers are raw pointers, sizes are ints/size_t, errors are negative
+ * ints like the reference's (-1 I/O or EOF, -2 capacity; see bytes.h:75-105).
+ *
+ * Conventions
+ *   - `dev` pointers are HIP device pointers (from dwtx_malloc or any HIP
+ *     allocator, e.g. a torch tensor's data_ptr()).  `host` pointers are plain
+ *     host memory.
+ *   - Images inside the library are PLANAR int32: plane p = image*C + channel,
+ *     each plane H rows of W ints, row pitch W (dense).  The reference keeps
+ *     interleaved int buffers (image.h:12-15); dwtx_planes_from_pixels /
+ *     dwtx_pixels_from_planes convert at the edge, fused with the colour
+ *     transform.
+ *   - All functions are asynchronous on the context's stream unless they
+ *     return data to the host; dwtx_sync() waits.
+ *   - Thread-compatible: one context per host thread.
+ */
+#ifndef DWTX_H
+#define DWTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWTX_OK            0
+#define DWTX_ERR_IO       -1   /* bytes.h:79-83,99-103 */
+#define DWTX_ERR_CAPACITY -2   /* bytes.h:77-78 */
+#define DWTX_ERR_ARG      -3   /* encode.c:139-146, decode.c:145-159 (exit code 1 there) */
+#define DWTX_ERR_DEVICE   -4   /* HIP runtime failure; dwtx_last_error() has the text */
+#define DWTX_ERR_NOMEM    -5
+
+#define DWTX_MAX_LEVELS 16
+#define DWTX_MIN_LEN     8     /* encode.c:144, decode.c:157 */
+
+typedef struct dwtx_ctx dwtx_ctx;
+
+/* Level geometry, utils.h:17-40.  Index 0 = root LL, index `levels` = full image. */
+typedef struct dwtx_geom {
+	int levels;
+	int widths[DWTX_MAX_LEVELS];
+	int heights[DWTX_MAX_LEVELS];
+	int pixels[DWTX_MAX_LEVELS];
+	int lengths[DWTX_MAX_LEVELS];
+} dwtx_geom;
+
+/* encode.c:175-180,226-230 stderr counters */
+typedef struct dwtx_stats {
+	int meta_bits;
+	int root_bits;
+	int total_bits;
+	int kib;
+	int levels;
+	int planes[3];
+} dwtx_stats;
+
+/* ---- context / memory ---------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  `stream` is an existing
+ * hipStream_t to run on (e.g. torch's current stream), or NULL to create one. */
+int dwtx_ctx_create(int device, void *stream, dwtx_ctx **ctx);
+void dwtx_ctx_destroy(dwtx_ctx *ctx);
+const char *dwtx_last_error(void);
+int dwtx_sync(dwtx_ctx *ctx);
+void *dwtx_stream(dwtx_ctx *ctx);
+
+void *dwtx_malloc(dwtx_ctx *ctx, size_t bytes);
+void dwtx_free(dwtx_ctx *ctx, void *dev);
+int dwtx_upload(dwtx_ctx *ctx, void *dev, const void *host, size_t bytes);
+int dwtx_download(dwtx_ctx *ctx, void *host, const void *dev, size_t bytes);
+
+/* ---- host-side geometry --------------------------------------------------- */
+
+/* utils.h:28-40 compute_lengths(): same argument order and return value. */
+int dwtx_compute_lengths(int *lengths, int *pixels, int *widths, int *heights, int W, int H, int N0);
+int dwtx_geometry(dwtx_geom *g, int W, int H);
+
+/* ---- stage kernels (device buffers, batches of n images) ------------------ */
+
+/* pnm.h:69-74 widening + image.h:67-72 ycocg_from_rgb (C==3): interleaved
+ * 8-bit pixels [n][H][W][C] -> planar int32 [n*C][H][W]. */
+int dwtx_planes_from_pixels(dwtx_ctx *ctx, int32_t *dev_planes, const uint8_t *dev_pix, int W, int H, int C, int n);
+/* image.h:74-79 rgb_from_ycocg (with its clamps, image.h:41-43) + pnm.h:108 clamp. */
+int dwtx_pixels_from_planes(dwtx_ctx *ctx, uint8_t *dev_pix, const int32_t *dev_planes, int W, int H, int C, int n);
+
+/* encode.c:16-30 transformation(): multi-level forward CDF 5/3 of `nplanes`
+ * planar W*H images.  dev_in is preserved; dev_out receives the Mallat pyramid. */
+int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_in, int W, int H, int nplanes);
+/* decode.c:16-30 transformation(): inverse.  dev_in (pyramid) is preserved. */
+int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_in, int W, int H, int nplanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""CPU tests: the oracle (our C restatement) against the committed goldens that the
+real reference produced (tests/golden/make_golden.py), and — when oracle/_ref is
+present — against the reference binaries directly."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+G = json.load(open(os.path.join(orc.GOLDEN, "golden.json")))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def case_input(rec):
+    if rec["seed"] is None:
+        return orc.read_pnm(os.path.join(orc.GOLDEN, "smpte.pnm"))
+    return orc.synth(rec["W"], rec["H"], rec["C"], rec["seed"], rec["kind"])
+
+
+SMALL = [k for k, v in G.items() if v["W"] * v["H"] <= 1024 * 1024]
+
+
+@pytest.mark.parametrize("name", sorted(G))
+def test_golden_encode_decode(name):
+    rec = G[name]
+    if name not in SMALL and os.environ.get("DWT_FULL_GOLDEN", "1") == "0":
+        pytest.skip("large golden skipped")
+    pix = case_input(rec)
+    assert sha(pix.tobytes()) == rec["input_sha256"], "synthetic generator drifted"
+    data, st = orc.encode(pix, rec["capacity"])
+    assert len(data) == rec["dwt_len"]
+    assert sha(data) == rec["dwt_sha256"]
+    if "dwt_file" in rec:
+        assert data == open(os.path.join(orc.GOLDEN, rec["dwt_file"]), "rb").read()
+    lines = [f"{st.meta_bits} bits for meta data", f"{st.root_bits} bits for root image",
+             f"{st.total_bits} bits ({st.kib} KiB) encoded"]
+    assert lines == rec["encode_stderr"]
+    px = rec["pixels_arg"]
+    back = orc.decode(data, -1 if px is None else px)
+    assert back.shape[:2] == (rec["dec_H"], rec["dec_W"])
+    assert sha(back.tobytes()) == rec["dec_sha256"]
+    assert bool(back.shape == pix.shape and (back == pix).all()) == rec["lossless"]
+
+
+def test_smpte_known_answers():
+    # SURVEY.md §4 table
+    pix = orc.read_pnm(os.path.join(orc.GOLDEN, "smpte.pnm"))
+    data, st = orc.encode(pix)
+    assert len(data) == 10147
+    assert sha(data) == "2ac1d6b75498f2982c2fbf80edc9ea74c956affc8d45584597de530b41c9dfd0"
+    assert data[:16].hex() == "57363f01ef009866940c7979c16c9221"
+    assert (st.meta_bits, st.root_bits, st.total_bits) == (48, 559, 81174)
+    assert list(st.planes) == [8, 9, 9] and st.levels == 6
+
+
+def test_geometry():
+    g = orc.geometry(4096, 4096)
+    assert g.levels == 10 and g.widths[0] == 4 and g.widths[10] == 4096
+    g = orc.geometry(320, 240)
+    assert g.levels == 6 and (g.widths[0], g.heights[0]) == (5, 4)
+    g = orc.geometry(1920, 1080)
+    assert g.levels == 8 and (g.widths[0], g.heights[0]) == (8, 5)
+    assert list(g.heights[:9]) == [5, 9, 17, 34, 68, 135, 270, 540, 1080]
+    g = orc.geometry(8, 8)
+    assert g.levels == 1 and g.lengths[1] == 8 and g.lengths[0] == 4
+
+
+def test_lifting_roundtrip_and_edges():
+    rng = np.random.default_rng(1)
+    for (H, W, Cn) in [(8, 8, 1), (9, 13, 3), (16, 31, 1), (33, 8, 3), (100, 75, 1)]:
+        img = rng.integers(-300, 300, size=(H, W, Cn), dtype=np.int32)
+        pyr = orc.forward(img)
+        assert (orc.inverse(pyr) == img).all()
+    # odd length: last even sample is not updated (cdf53.h:19-21, M = N & ~1)
+    line = np.arange(9, dtype=np.int32).reshape(1, 9, 1) ** 2
+    col = np.repeat(line, 8, axis=0)
+    pyr = orc.forward(col)
+    # after the row pass the last low-pass sample equals the input sample x[8]=64; the
+    # column pass on constant columns leaves low-pass rows unchanged
+    assert pyr[0, 4, 0] == 64
+
+
+def test_hilbert_is_a_curve():
+    n = 16
+    pts = [orc.hilbert(n, d) for d in range(n * n)]
+    assert sorted(pts) == [(x, y) for x in range(n) for y in range(n)]
+    for a, b in zip(pts, pts[1:]):
+        assert abs(a[0] - b[0]) + abs(a[1] - b[1]) == 1
+    assert pts[:4] == [(0, 0), (1, 0), (1, 1), (0, 1)]
+
+
+def test_truncation_is_prefix_and_decodes():
+    pix = orc.synth(131, 77, 3, 5, 0)
+    full, _ = orc.encode(pix)
+    for cap in (1, 6, 7, 64, 500, 5000, len(full) - 1, len(full), len(full) + 5):
+        data, _ = orc.encode(pix, cap)
+        assert data == full[:cap]
+        if cap >= 500:   # the 9x5 root of 3 channels alone needs > 64 bytes
+            assert orc.decode(data) is not None
+
+
+def test_flat_image_quirk():
+    # all-zero detail -> decoder emits widths[1] x heights[1]
+    pix = np.full((16, 100, 3), 77, dtype=np.uint8)
+    data, st = orc.encode(pix)
+    assert list(st.planes) == [0, 0, 0]
+    back = orc.decode(data)
+    assert back.shape == (8, 50, 3)
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("shape", [(8, 8, 1), (8, 9, 3), (300, 17, 1), (53, 37, 3), (77, 131, 3), (64, 64, 1),
+                                   (16, 100, 3), (15, 15, 1), (240, 320, 3)])
+def test_against_reference_binaries(tmp_path, shape):
+    H, W, Cn = shape
+    for kind in (0, 1):
+        pix = orc.synth(W, H, Cn, 11 + kind, kind)
+        src, dwt, dec = (str(tmp_path / n) for n in ("i.pnm", "o.dwt", "o.pnm"))
+        orc.write_pnm(src, pix)
+        for cap in (0, 97, 1500):
+            cmd = [os.path.join(orc.REF_DIR, "encode"), src, dwt] + ([str(cap)] if cap else [])
+            subprocess.run(cmd, capture_output=True, check=True)
+            ref = open(dwt, "rb").read()
+            mine, _ = orc.encode(pix, cap)
+            assert mine == ref
+            r = subprocess.run([os.path.join(orc.REF_DIR, "decode"), dwt, dec], capture_output=True)
+            back = orc.decode(ref)
+            if r.returncode:
+                assert back is None
+            else:
+                assert (orc.read_pnm(dec) == back).all() and orc.read_pnm(dec).shape == back.shape

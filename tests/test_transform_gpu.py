@@ -1,0 +1,79 @@
+"""GPU parity: colour transform + multi-level CDF 5/3 through the C ABI vs the oracle."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 8, 1), (8, 9, 3), (9, 8, 1), (15, 15, 3), (16, 16, 1), (53, 37, 3), (77, 131, 3), (300, 17, 1),
+          (17, 300, 3), (255, 257, 1), (257, 255, 3), (64, 64, 3), (240, 320, 3), (129, 1000, 1), (1080, 1920, 3),
+          (540, 9, 1)]
+
+
+def to_planes(a):
+    """[H,W,C] interleaved -> [C,H,W]"""
+    return np.ascontiguousarray(np.moveaxis(a, 2, 0))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_matches_oracle(ctx, shape):
+    import torch
+
+    H, W, Cn = shape
+    pix = orc.synth(W, H, Cn, 3, 0)
+    coef, _, _ = orc.stage_dump(pix)
+    t = torch.from_numpy(pix[None]).cuda()
+    planes = ctx.planes_from_pixels(t)
+    pyr = ctx.transformation_fwd(planes)
+    got = pyr.cpu().numpy()
+    assert (got == to_planes(coef)).all()
+    back = ctx.transformation_inv(pyr)
+    assert torch.equal(back, planes)
+    out = ctx.pixels_from_planes(back, Cn)
+    assert (out.cpu().numpy()[0] == pix).all()
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (33, 71), (128, 96), (511, 513)])
+def test_random_int_planes_batch(ctx, shape):
+    """Batch of planes with full-range-ish ints: forward equals the oracle, inverse restores."""
+    import torch
+
+    H, W = shape
+    rng = np.random.default_rng(5)
+    P = 5
+    a = rng.integers(-5000, 5000, size=(P, H, W), dtype=np.int32)
+    want = np.stack([orc.forward(a[p][:, :, None])[:, :, 0] for p in range(P)])
+    pyr = ctx.transformation_fwd(torch.from_numpy(a).cuda())
+    assert (pyr.cpu().numpy() == want).all()
+    back = ctx.transformation_inv(pyr)
+    assert (back.cpu().numpy() == a).all()
+    # inverse of an arbitrary (non-transform) pyramid also matches the oracle
+    inv_want = np.stack([orc.inverse(a[p][:, :, None])[:, :, 0] for p in range(P)])
+    inv_got = ctx.transformation_inv(torch.from_numpy(a).cuda())
+    assert (inv_got.cpu().numpy() == inv_want).all()
+
+
+def test_4096_gray_roundtrip_and_checksum(ctx):
+    """BASELINE config B size: round trip + checksum against the oracle's pyramid."""
+    import torch
+
+    pix = orc.synth(4096, 4096, 1, 0, 0)
+    coef, _, _ = orc.stage_dump(pix)
+    t = torch.from_numpy(pix[None]).cuda()
+    planes = ctx.planes_from_pixels(t)
+    pyr = ctx.transformation_fwd(planes)
+    assert (pyr.cpu().numpy()[0] == coef[:, :, 0]).all()
+    assert torch.equal(ctx.transformation_inv(pyr), planes)
+
+
+def test_small_inverse_root_only(ctx):
+    """decode.c quirk: a root-only decode still runs one inverse level on a <8 image."""
+    import torch
+
+    rng = np.random.default_rng(2)
+    for (H, W) in [(4, 5), (5, 8), (4, 4), (7, 6)]:
+        a = rng.integers(-100, 100, size=(2, H, W), dtype=np.int32)
+        want = np.stack([orc.inverse(a[p][:, :, None])[:, :, 0] for p in range(2)])
+        got = ctx.transformation_inv(torch.from_numpy(a).cuda())
+        assert (got.cpu().numpy() == want).all()
