@@ -59,7 +59,7 @@ class Context:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         h = C.c_void_p()
-        _check(self.lib.dwtx_ctx_create(device, C.c_void_p(stream), C.byref(h)), "dwtx_ctx_create")
+        _check(self.lib.dwtx_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)), "dwtx_ctx_create_on_stream")
         self.h = h
 
     def close(self):

@@ -37,7 +37,8 @@ class Stats(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/dwtx.h declares
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
-    "dwtx_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "dwtx_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "dwtx_ctx_create_on_stream": (_i, [_i, _vp, C.POINTER(_vp)]),
     "dwtx_ctx_destroy": (None, [_vp]),
     "dwtx_last_error": (C.c_char_p, []),
     "dwtx_sync": (_i, [_vp]),

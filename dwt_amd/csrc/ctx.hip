@@ -21,7 +21,7 @@ extern "C" const char *dwtx_last_error(void)
 	return g_err;
 }
 
-extern "C" int dwtx_ctx_create(int device, void *stream, dwtx_ctx **out)
+static int ctx_create(int device, void *stream, bool make_stream, dwtx_ctx **out)
 {
 	if (!out)
 		return DWTX_ERR_ARG;
@@ -36,7 +36,7 @@ extern "C" int dwtx_ctx_create(int device, void *stream, dwtx_ctx **out)
 	if (!c)
 		return DWTX_ERR_NOMEM;
 	c->device = device;
-	if (stream) {
+	if (!make_stream) {
 		c->stream = (hipStream_t)stream;
 		c->own_stream = false;
 	} else {
@@ -50,6 +50,16 @@ extern "C" int dwtx_ctx_create(int device, void *stream, dwtx_ctx **out)
 	}
 	*out = c;
 	return DWTX_OK;
+}
+
+extern "C" int dwtx_ctx_create(int device, dwtx_ctx **out)
+{
+	return ctx_create(device, nullptr, true, out);
+}
+
+extern "C" int dwtx_ctx_create_on_stream(int device, void *stream, dwtx_ctx **out)
+{
+	return ctx_create(device, stream, false, out);
 }
 
 extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)

@@ -64,9 +64,11 @@ typedef struct dwtx_stats {
 
 /* ---- context / memory ---------------------------------------------------- */
 
-/* Create a context on HIP device `device`.  `stream` is an existing
- * hipStream_t to run on (e.g. torch's current stream), or NULL to create one. */
-int dwtx_ctx_create(int device, void *stream, dwtx_ctx **ctx);
+/* Create a context on HIP device `device` with a stream of its own. */
+int dwtx_ctx_create(int device, dwtx_ctx **ctx);
+/* Same, but run on an existing hipStream_t (e.g. torch's current stream);
+ * NULL means the device's default stream. */
+int dwtx_ctx_create_on_stream(int device, void *stream, dwtx_ctx **ctx);
 void dwtx_ctx_destroy(dwtx_ctx *ctx);
 const char *dwtx_last_error(void);
 int dwtx_sync(dwtx_ctx *ctx);
