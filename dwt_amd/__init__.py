@@ -115,3 +115,30 @@ class Context:
             out = torch.empty_like(pyr)
         _check(self.lib.dwtx_transformation_inv(self.h, _ptr(out), _ptr(pyr), W, H, P), "dwtx_transformation_inv")
         return out
+
+    def linearization(self, pyr):
+        """encode.c:32 linearization: pyramid [P,H,W] -> Hilbert-linearised [P,H*W]."""
+        torch = self.torch
+        P, H, W = pyr.shape
+        assert pyr.dtype == torch.int32 and pyr.is_contiguous()
+        out = torch.empty((P, H * W), dtype=torch.int32, device=self.device)
+        _check(self.lib.dwtx_linearization(self.h, _ptr(out), _ptr(pyr), W, H, P), "dwtx_linearization")
+        return out
+
+    def reconstruction(self, lin, W, H, C_, levels_out=None, missing=None):
+        """decode.c:32 reconstruction: [n*C, W*H] -> pyramid [n*C, h', w'] of the first levels_out levels."""
+        torch = self.torch
+        P = lin.shape[0]
+        n = P // C_
+        g = geometry(W, H)
+        if levels_out is None:
+            levels_out = g.levels
+        ow, oh = g.widths[levels_out], g.heights[levels_out]
+        out = torch.empty((P, oh, ow), dtype=torch.int32, device=self.device)
+        mp = C.c_void_p(0)
+        if missing is not None:
+            assert missing.dtype == torch.int32 and missing.numel() == n * 48 and missing.is_contiguous()
+            mp = _ptr(missing)
+        _check(self.lib.dwtx_reconstruction(self.h, _ptr(out), _ptr(lin), mp, levels_out, W, H, C_, n),
+               "dwtx_reconstruction")
+        return out

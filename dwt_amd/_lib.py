@@ -53,6 +53,8 @@ SYMBOLS = {
     "dwtx_pixels_from_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dwtx_transformation_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "dwtx_linearization": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "dwtx_reconstruction": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
 }
 
 _lib = None

@@ -68,6 +68,7 @@ extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 		return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	dwtx_free_plans(c);
 	for (int i = 0; i < DWTX_SCRATCH_SLOTS; ++i)
 		if (c->scratch[i])
 			(void)hipFree(c->scratch[i]);

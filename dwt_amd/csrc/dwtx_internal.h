@@ -8,13 +8,18 @@
 
 #define DWTX_SCRATCH_SLOTS 24
 
+struct dwtx_linplan;
+
 struct dwtx_ctx {
 	int device;
 	hipStream_t stream;
 	bool own_stream;
 	void *scratch[DWTX_SCRATCH_SLOTS];
 	size_t scratch_bytes[DWTX_SCRATCH_SLOTS];
+	dwtx_linplan *plans;   // per-geometry Hilbert block tables (linearize.hip)
 };
+
+void dwtx_free_plans(dwtx_ctx *ctx);
 
 void dwtx_set_error(const char *fmt, ...);
 // grow-only per-slot device scratch; contents undefined after a grow

@@ -1,0 +1,335 @@
+// linearize.hip — Hilbert-order linearisation of the wavelet pyramid and its
+// inverse (encode.c:32-58 linearization, decode.c:32-65 reconstruction,
+// hilbert.h:15-34).
+//
+// The reference walks d = 0..n*n-1 serially, calls hilbert(n, d) and keeps a
+// running output index for the points that fall inside the level's L-shaped
+// detail ring.  Here every point is independent: the Hilbert curve visits every
+// aligned 2^k x 2^k square contiguously, so the curve is cut into blocks of
+// 1024 consecutive d (one 32x32 square each); the number of ring points in a
+// square is a closed-form rectangle intersection, an exclusive scan over the
+// blocks (done once per image geometry, cached in the context) gives each
+// block's first output slot, and inside a block the slot is a ballot/popcount
+// rank.  One workgroup handles one block for one plane; lanes take consecutive
+// d so the linear side of the copy is a coalesced stream and the pyramid side
+// touches a compact 32x32 tile.
+#include "dwtx_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+constexpr int BLK_LOG2 = 5;                 // 32x32 squares
+constexpr int THREADS = 256;
+
+struct LinGeom {
+	int levels;             // levels of the full image
+	int W, H;
+	int widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], lengths[DWTX_MAX_LEVELS];
+	int blk_first[DWTX_MAX_LEVELS + 1];  // first global block id of ring level l
+	int blk_pts_log2[DWTX_MAX_LEVELS];   // log2(points per block) of ring level l (10, or less for tiny levels)
+};
+
+// hilbert.h:15-34 — curve index -> (x, y) on an n*n grid, branch-free.
+// For x < s: s-1-x == (s-1) ^ x, and adding s is an OR.
+__device__ __forceinline__ void hilbert_d2xy(int n, unsigned d, int &xo, int &yo)
+{
+	unsigned x = 0, y = 0;
+	for (unsigned s = 1; s < (unsigned)n; s <<= 1) {
+		const unsigned rx = (d >> 1) & 1u;
+		const unsigned ry = (d ^ rx) & 1u;
+		const unsigned flip = (rx & ~ry & 1u) ? (s - 1) : 0u;
+		x ^= flip;
+		y ^= flip;
+		const unsigned sw = ry ? 0u : (x ^ y);
+		x ^= sw;
+		y ^= sw;
+		x |= rx ? s : 0u;
+		y |= ry ? s : 0u;
+		d >>= 2;
+	}
+	xo = (int)x;
+	yo = (int)y;
+}
+
+__device__ __forceinline__ int overlap(int lo, int len, int bound)
+{
+	// |[lo, lo+len) ∩ [0, bound)|
+	int hi = lo + len;
+	hi = hi < bound ? hi : bound;
+	return hi > lo ? hi - lo : 0;
+}
+
+__device__ __forceinline__ int level_of_block(const LinGeom &g, int b)
+{
+	int l = 0;
+	while (l + 1 < g.levels && b >= g.blk_first[l + 1])
+		++l;
+	return l;
+}
+
+// ring points inside curve block `lb` of ring level l
+__device__ __forceinline__ int ring_points_in_block(const LinGeom &g, int l, int lb)
+{
+	const int n = g.lengths[l + 1];
+	const int pl2 = g.blk_pts_log2[l];
+	const int side = 1 << (pl2 >> 1);
+	int x, y;
+	hilbert_d2xy(n, (unsigned)lb << pl2, x, y);
+	x &= ~(side - 1);
+	y &= ~(side - 1);
+	const int full = overlap(x, side, g.widths[l + 1]) * overlap(y, side, g.heights[l + 1]);
+	const int ll = overlap(x, side, g.widths[l]) * overlap(y, side, g.heights[l]);
+	return full - ll;
+}
+
+// one thread per block: counts[b] (scanned afterwards on one workgroup)
+__global__ void k_block_counts(LinGeom g, int *__restrict__ counts, int nblocks)
+{
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nblocks)
+		return;
+	const int l = level_of_block(g, b);
+	counts[b] = ring_points_in_block(g, l, b - g.blk_first[l]);
+}
+
+// exclusive scan of counts per level, single workgroup (geometry set-up only)
+__global__ __launch_bounds__(1024) void k_block_scan(LinGeom g, int *__restrict__ counts)
+{
+	__shared__ int wsum[16];
+	__shared__ int carry;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int l = 0; l < g.levels; ++l) {
+		const int first = g.blk_first[l], nb = g.blk_first[l + 1] - first;
+		if (threadIdx.x == 0)
+			carry = 0;
+		__syncthreads();
+		for (int base = 0; base < nb; base += 1024) {
+			const int i = base + threadIdx.x;
+			const int v = i < nb ? counts[first + i] : 0;
+			int inc = v;
+			for (int o = 1; o < 64; o <<= 1) {
+				const int t = __shfl_up(inc, o);
+				if (lane >= o)
+					inc += t;
+			}
+			if (lane == 63)
+				wsum[wv] = inc;
+			__syncthreads();
+			int woff = 0;
+			for (int k = 0; k < wv; ++k)
+				woff += wsum[k];
+			const int c = carry;
+			if (i < nb)
+				counts[first + i] = c + woff + inc - v;
+			__syncthreads();
+			if (threadIdx.x == 1023)
+				carry = c + woff + inc;
+			__syncthreads();
+		}
+	}
+}
+
+template <bool INVERSE>
+__global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__restrict__ blockbase,
+	int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch,
+	const int *__restrict__ missing, int C)
+{
+	__shared__ int wcount[THREADS / 64];
+	const int b = blockIdx.x;
+	const int plane = blockIdx.y;
+	const int l = level_of_block(g, b);
+	const int lb = b - g.blk_first[l];
+	const int n = g.lengths[l + 1];
+	const int pl2 = g.blk_pts_log2[l];
+	const int npts = 1 << pl2;
+	const int total = ring_points_in_block(g, l, lb);   // uniform
+	if (total == 0)
+		return;
+	const bool full = total == npts;
+	const int w0 = g.widths[l], h0 = g.heights[l], w1 = g.widths[l + 1], h1 = g.heights[l + 1];
+	int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
+	int *pp = pyr + plane * pyr_ps;
+	int bias = 0;
+	if (INVERSE && missing) {
+		// decode.c:51-58: planes never decoded leave a dead zone; recentre non-zero values
+		const int m = missing[(plane / C) * 48 + (plane % C) * 16 + l] - 2;
+		bias = m >= 0 ? 1 << m : 0;
+	}
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int running = 0;
+	for (int base = 0; base < npts; base += THREADS) {
+		const int i = base + threadIdx.x;
+		int x = 0, y = 0;
+		bool ok = false;
+		if (i < npts) {
+			hilbert_d2xy(n, ((unsigned)lb << pl2) + (unsigned)i, x, y);
+			ok = x < w1 && y < h1 && (x >= w0 || y >= h0);
+		}
+		int slot;
+		if (full) {
+			slot = i;
+		} else {
+			const unsigned long long mask = __ballot(ok);
+			const int before = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+			if (lane == 0)
+				wcount[wv] = __builtin_popcountll(mask);
+			__syncthreads();
+			int woff = 0, all = 0;
+			for (int k = 0; k < THREADS / 64; ++k) {
+				const int c = wcount[k];
+				woff += k < wv ? c : 0;
+				all += c;
+			}
+			slot = running + woff + before;
+			running += all;
+			__syncthreads();
+		}
+		if (ok) {
+			if (INVERSE) {
+				int v = lp[slot];
+				if (bias && v)
+					v += v < 0 ? -bias : bias;
+				pp[(long)y * ppitch + x] = v;
+			} else {
+				lp[slot] = pp[(long)y * ppitch + x];
+			}
+		}
+	}
+}
+
+// root LL in raster order (encode.c:37-45 / decode.c:36-44)
+template <bool INVERSE>
+__global__ void k_root_copy(int w0, int h0, int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch)
+{
+	const int plane = blockIdx.y;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= w0 * h0)
+		return;
+	const int y = i / w0, x = i - y * w0;
+	int *lp = lin + plane * lin_ps + i;
+	int *pp = pyr + plane * pyr_ps + (long)y * ppitch + x;
+	if (INVERSE)
+		*pp = *lp;
+	else
+		*lp = *pp;
+}
+
+} // namespace
+
+// ---- geometry plans, cached per context --------------------------------------
+
+struct dwtx_linplan {
+	int W, H;
+	LinGeom g;
+	int nblocks;
+	int *d_blockbase;
+	dwtx_linplan *next;
+};
+
+static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
+{
+	for (dwtx_linplan *p = ctx->plans; p; p = p->next)
+		if (p->W == W && p->H == H) {
+			*out = p;
+			return DWTX_OK;
+		}
+	dwtx_linplan *p = (dwtx_linplan *)calloc(1, sizeof(*p));
+	if (!p)
+		return DWTX_ERR_NOMEM;
+	p->W = W;
+	p->H = H;
+	LinGeom &g = p->g;
+	g.W = W;
+	g.H = H;
+	g.levels = dwtx_compute_lengths(g.lengths, g.pixels, g.widths, g.heights, W, H, DWTX_MIN_LEN);
+	int nb = 0;
+	for (int l = 0; l < g.levels; ++l) {
+		const int n = g.lengths[l + 1];
+		int nl2 = 0;
+		while ((1 << nl2) < n)
+			++nl2;
+		const int pl2 = 2 * nl2 < 2 * BLK_LOG2 ? 2 * nl2 : 2 * BLK_LOG2;
+		g.blk_pts_log2[l] = pl2;
+		g.blk_first[l] = nb;
+		nb += (int)(((long)n * n) >> pl2);
+	}
+	g.blk_first[g.levels] = nb;
+	p->nblocks = nb;
+	if (hipMalloc((void **)&p->d_blockbase, sizeof(int) * (size_t)(nb > 0 ? nb : 1)) != hipSuccess) {
+		free(p);
+		dwtx_set_error("plan hipMalloc failed");
+		return DWTX_ERR_NOMEM;
+	}
+	hipLaunchKernelGGL(k_block_counts, dim3(dwtx_cdiv(nb, 256)), dim3(256), 0, ctx->stream, g, p->d_blockbase, nb);
+	hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, ctx->stream, g, p->d_blockbase);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		dwtx_set_error("plan kernels -> %s", hipGetErrorString(e));
+		(void)hipFree(p->d_blockbase);
+		free(p);
+		return DWTX_ERR_DEVICE;
+	}
+	p->next = ctx->plans;
+	ctx->plans = p;
+	*out = p;
+	return DWTX_OK;
+}
+
+void dwtx_free_plans(dwtx_ctx *ctx)
+{
+	dwtx_linplan *p = ctx->plans;
+	while (p) {
+		dwtx_linplan *n = p->next;
+		(void)hipFree(p->d_blockbase);
+		free(p);
+		p = n;
+	}
+	ctx->plans = nullptr;
+}
+
+extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes)
+{
+	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || nplanes < 1 || nplanes > 65535)
+		return DWTX_ERR_ARG;
+	dwtx_linplan *p;
+	int rc = get_plan(ctx, W, H, &p);
+	if (rc)
+		return rc;
+	const LinGeom &g = p->g;
+	const long ps = (long)W * H;
+	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
+		g.widths[0], g.heights[0], lin, ps, const_cast<int *>(pyr), ps, W);
+	hipLaunchKernelGGL(k_ring_copy<false>, dim3(p->nblocks, nplanes), dim3(THREADS), 0, ctx->stream,
+		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1);
+	DWTX_LAUNCH_CHECK();
+	return DWTX_OK;
+}
+
+extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
+	int levels_out, int W, int H, int C, int n)
+{
+	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || (C != 1 && C != 3) || n < 1 || n * C > 65535)
+		return DWTX_ERR_ARG;
+	dwtx_linplan *p;
+	int rc = get_plan(ctx, W, H, &p);
+	if (rc)
+		return rc;
+	LinGeom g = p->g;
+	if (levels_out < 0 || levels_out > g.levels)
+		return DWTX_ERR_ARG;
+	const int ow = g.widths[levels_out], oh = g.heights[levels_out];
+	const long lin_ps = (long)W * H;
+	const long pyr_ps = (long)ow * oh;
+	const int nplanes = n * C;
+	hipLaunchKernelGGL(k_root_copy<true>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
+		g.widths[0], g.heights[0], const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow);
+	if (levels_out > 0) {
+		g.levels = levels_out;   // only rings 0..levels_out-1 are rebuilt
+		hipLaunchKernelGGL(k_ring_copy<true>, dim3(g.blk_first[levels_out], nplanes), dim3(THREADS), 0, ctx->stream,
+			g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C);
+	}
+	DWTX_LAUNCH_CHECK();
+	return DWTX_OK;
+}

@@ -99,6 +99,18 @@ int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_
 /* decode.c:16-30 transformation(): inverse.  dev_in (pyramid) is preserved. */
 int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_in, int W, int H, int nplanes);
 
+/* encode.c:32-58 linearization(): Mallat pyramid planes [nplanes][H][W] ->
+ * Hilbert-linearised planes [nplanes][W*H] (root raster first, then the detail
+ * ring of each level in curve order, hilbert.h:15-34). */
+int dwtx_linearization(dwtx_ctx *ctx, int32_t *dev_lin, const int32_t *dev_pyr, int W, int H, int nplanes);
+/* decode.c:32-65 reconstruction(): the inverse scatter, for the first
+ * `levels_out` levels only (output planes are widths[levels_out] x
+ * heights[levels_out], dense).  dev_missing is NULL or int[n][3][16] as in
+ * decode.c:193-196 (planes not decoded per channel and level -> dequantisation
+ * bias, decode.c:51-58). */
+int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *dev_pyr, const int32_t *dev_lin, const int *dev_missing,
+	int levels_out, int W, int H, int C, int n);
+
 #ifdef __cplusplus
 }
 #endif

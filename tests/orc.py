@@ -37,6 +37,8 @@ def lib():
         L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_inverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_hilbert.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_reconstruct.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Geom), C.c_int, C.c_int]
+        L.orc_linearize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Geom), C.c_int]
         _lib = L
     return _lib
 
@@ -105,6 +107,29 @@ def inverse(pyr):
     H, W, Cn = a.shape
     lib().orc_inverse(a.ctypes.data, W, H, Cn, 8)
     return a
+
+
+def linearize(pyr):
+    """int32 [H,W,C] interleaved pyramid -> [C, H*W]."""
+    H, W, Cn = pyr.shape
+    g = geometry(W, H)
+    pyr = np.ascontiguousarray(pyr, dtype=np.int32)
+    lin = np.empty((Cn, H * W), dtype=np.int32)
+    lib().orc_linearize(lin.ctypes.data, pyr.ctypes.data, C.byref(g), Cn)
+    return lin
+
+
+def reconstruct(lin, W, H, levels_out, missing=None):
+    """[C, W*H] -> interleaved pyramid [h', w', C] of the first levels_out levels (decode.c:32-65)."""
+    Cn = lin.shape[0]
+    g = geometry(W, H)
+    ow, oh = g.widths[levels_out], g.heights[levels_out]
+    rows = [np.ascontiguousarray(lin[c], dtype=np.int32) for c in range(Cn)]
+    ptrs = (C.c_void_p * Cn)(*[r.ctypes.data for r in rows])
+    miss = np.zeros(48, dtype=np.int32) if missing is None else np.ascontiguousarray(missing, dtype=np.int32)
+    out = np.empty((oh, ow, Cn), dtype=np.int32)
+    lib().orc_reconstruct(out.ctypes.data, ptrs, miss.ctypes.data, C.byref(g), levels_out, Cn)
+    return out
 
 
 def hilbert(n, d):
