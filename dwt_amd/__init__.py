@@ -10,7 +10,7 @@ raise.
 import ctypes as C
 
 from . import _lib
-from ._lib import Geom, Stats, LIB_PATH  # noqa: F401
+from ._lib import Geom, Stats, StreamInfo, LIB_PATH  # noqa: F401
 
 __all__ = ["Context", "DwtxError", "compute_lengths", "geometry", "Geom", "Stats"]
 
@@ -142,3 +142,29 @@ class Context:
         _check(self.lib.dwtx_reconstruction(self.h, _ptr(out), _ptr(lin), mp, levels_out, W, H, C_, n),
                "dwtx_reconstruction")
         return out
+
+    def encode_planes(self, lin, W, H, C_, capacity=0, out_stride=None):
+        """encode.c:166-221 on linearised planes [n*C, W*H] -> (list of bytes, list of StreamInfo)."""
+        import numpy as np
+
+        torch = self.torch
+        n = lin.shape[0] // C_
+        assert lin.dtype == torch.int32 and lin.is_contiguous()
+        if out_stride is None:
+            out_stride = capacity if capacity > 0 else 2 * W * H * C_ + 4096
+            out_stride = (out_stride + 8 + 3) // 4 * 4
+        out = torch.empty((n, out_stride), dtype=torch.uint8, device=self.device)
+        info = torch.empty((n, C.sizeof(StreamInfo)), dtype=torch.uint8, device=self.device)
+        _check(self.lib.dwtx_encode_planes(self.h, _ptr(lin), W, H, C_, n, capacity, _ptr(out), out_stride, _ptr(info)),
+               "dwtx_encode_planes")
+        raw = info.cpu().numpy()
+        infos = [StreamInfo.from_buffer_copy(raw[i].tobytes()) for i in range(n)]
+        host = out.cpu().numpy()
+        streams = []
+        for i in range(n):
+            if infos[i].error:
+                raise DwtxError(-3, "dwtx_encode_planes (more than 16 bit planes)")
+            if infos[i].nbytes > out_stride:
+                raise DwtxError(-2, "dwtx_encode_planes (out_stride too small)")
+            streams.append(host[i, : infos[i].nbytes].tobytes())
+        return streams, infos

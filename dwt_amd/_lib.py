@@ -23,6 +23,14 @@ class Geom(C.Structure):
     ]
 
 
+class StreamInfo(C.Structure):
+    _fields_ = [
+        ("planes", C.c_int * 3), ("pmax", C.c_int), ("segments", C.c_int), ("entries", C.c_int),
+        ("tokens", C.c_uint), ("order0", C.c_int), ("hdr_bits", C.c_uint), ("root_bits", C.c_uint),
+        ("total_bits", C.c_ulonglong), ("nbytes", C.c_ulonglong), ("error", C.c_int), ("pad", C.c_int),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("meta_bits", C.c_int),
@@ -55,6 +63,7 @@ SYMBOLS = {
     "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_linearization": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_reconstruction": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "dwtx_encode_planes": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp]),
 }
 
 _lib = None

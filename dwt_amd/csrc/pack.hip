@@ -1,0 +1,1029 @@
+// pack.hip — the encoder's entropy stage on the GPU: bit-plane coder
+// (encode.c:60-95), progressive plane schedule (encode.c:183-221), zero-run RLE
+// (rle.h:56-103), adaptive VLI (vli.h:67-84), LSB-first bit packing
+// (bits.h:58-78) and the root/header coder (encode.c:97-110,166-182).
+//
+// The reference is one serial loop: every coefficient visit may emit bits whose
+// position and length depend on everything emitted before (a shared zero-run
+// counter and a shared adaptive VLI order).  Here the stream is rebuilt from
+// data-parallel passes over a batch of images:
+//
+//   k_hist    one wave per 1024-coefficient tile: cumulative magnitude
+//             histogram cum[p] = #(|v| < 2^p) by ballot/popcount.  Every
+//             (tile, plane) symbol count — zeros, ones, refinement bits — is a
+//             difference of two entries, so the coefficients are read once here
+//             for all planes; max plane count per channel by atomicMax.
+//   k_plan    per image (serial, tiny): header + root image + plane counts
+//             written straight into the stream, the segment schedule, VLI order
+//             after the header.
+//   k_entries per image: an "entry" is (segment, tile).  Symbol counts per
+//             entry from the histograms, exclusive scans -> first token slot
+//             and refinement rank of every entry.
+//   k_tokens  one wave per entry: classify 64 coefficients per row at the
+//             entry's plane; every significant one becomes a token
+//             (zero run since the previous one in this tile, sign).
+//   k_carry   per image: segmented scan of pending zero runs across entries,
+//             segment ends (phantom terminators, rle.h:79-89) and the final
+//             flush; patches the first token of each entry.
+//   k_lut/k_chain*/k_orders  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0)
+//             is a scan over monotone maps on 32 states: lanes act as the 32
+//             start states, chunk maps are composed hierarchically.
+//   k_bitscan per image: exclusive scan of chunk bit totals -> bit offsets.
+//   k_emit    one lane per 64 tokens: sequential LSB-first bit writer over the
+//             lane's contiguous bit range, words merged with atomicOr.
+//   k_refine  one wave per entry: refinement bits, compacted through LDS.
+#include "dwtx_internal.h"
+
+#include <string.h>
+
+namespace {
+
+constexpr int TILE = 1024;
+constexpr int ROWS = TILE / 64;
+constexpr int NCUM = 32;              // cum[0..31]
+constexpr int MAX_PLANES = 16;        // 8-bit sources stay far below (checked in k_plan)
+constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
+constexpr int SUB = 64;               // tokens per lane
+constexpr int CHUNK = SUB * 64;       // tokens per wave
+constexpr int GROUP = 64;             // chunks per group
+
+constexpr unsigned F_SIGN = 1, F_HAS_SIGN = 2, F_BREAK = 4, F_FLUSH = 8, F_VOID = 16;
+
+struct PackGeom {
+	int levels, C, W, H;
+	long total;
+	int pixels[DWTX_MAX_LEVELS + 1];
+	int tile_first[DWTX_MAX_LEVELS + 1];   // tile_first[levels] = tiles per plane
+};
+
+struct ImgInfo {
+	int planes[3];
+	int pmax;
+	int K;                 // segments
+	int E;                 // entries
+	unsigned T;            // tokens
+	int order0;            // VLI order after header + root + plane counts
+	unsigned hdr_bits;
+	unsigned root_bits;
+	unsigned long long total_bits;
+	unsigned long long nbytes;
+	int error;
+	int pad;
+};
+
+struct Work {
+	// per plane
+	unsigned short *cum;        // [nplanes][NT][32]
+	int *planes_dev;            // [nplanes]
+	// per image
+	ImgInfo *info;              // [n]
+	int *seg_desc;              // [n][MAX_SEGS]   c | l<<4 | (p+1)<<8
+	int *seg_ebase;             // [n][MAX_SEGS+1]
+	unsigned *seg_refs;         // [n][MAX_SEGS]
+	unsigned long long *seg_rawoff; // [n][MAX_SEGS] bit offset of the segment's refinement block
+	unsigned *brk_tok;          // [n][MAX_SEGS] token index of the segment's break slot
+	// per entry
+	unsigned short *ent_ones, *ent_zeros, *ent_refs, *ent_tz;   // [n][ES]
+	unsigned *ent_tokbase;      // [n][ES+1]
+	unsigned *ent_refscum;      // [n][ES+1]
+	// per token
+	unsigned *tok_run;          // [n][TS]
+	unsigned char *tok_flag;    // [n][TS]
+	unsigned char *tok_ord;     // [n][TS]
+	// per chunk
+	unsigned char *sublut;      // [n][NCS*64][32]
+	unsigned char *lut;         // [n][NCS][32]
+	unsigned char *glut;        // [n][NGS][32]
+	unsigned char *chunk_entry; // [n][NCS]
+	unsigned char *group_entry; // [n][NGS]
+	unsigned long long *chunk_bits;    // [n][NCS]
+	unsigned long long *chunk_base;    // [n][NCS]
+	long ES, TS, NCS, NGS;
+	int NT;
+};
+
+__device__ __forceinline__ int lane_id()
+{
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+
+__device__ __forceinline__ int popc_below(unsigned long long m)
+{
+	return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+__device__ __forceinline__ int ilog2u(unsigned v) { return 31 - __builtin_clz(v); }
+
+// vli.h:67-84 in closed form: order o, value v -> o* 
+__device__ __forceinline__ int vli_top(int o, unsigned v) { return ilog2u(v + (1u << o)); }
+__device__ __forceinline__ int vli_next(int top) { return top >= 2 ? top - 2 : 0; }
+
+__device__ __forceinline__ void seg_unpack(int d, int &c, int &l, int &p)
+{
+	c = d & 15;
+	l = (d >> 4) & 15;
+	p = (d >> 8) - 1;
+}
+
+// ------------------------------------------------------------------ k_hist ---
+
+__global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
+{
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int plane = blockIdx.y;
+	if (tile >= w.NT)
+		return;
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
+	const long ring0 = g.pixels[l], ring1 = g.pixels[l + 1];
+	const long base = ring0 + (long)(tile - g.tile_first[l]) * TILE;
+	const int *src = lin + plane * g.total;
+	int cnt[NCUM];
+#pragma unroll
+	for (int p = 0; p < NCUM; ++p)
+		cnt[p] = 0;
+	unsigned mx = 0;
+	for (int r = 0; r < ROWS; ++r) {
+		const long i = base + r * 64 + lane;
+		const bool in = i < ring1;
+		const int v = in ? src[i] : 0;
+		const unsigned m = in ? (unsigned)(v < 0 ? -v : v) : 0xffffffffu;   // out-of-ring lanes count nowhere
+		mx |= in ? m : 0u;
+#pragma unroll
+		for (int p = 0; p < NCUM; ++p)
+			cnt[p] += __builtin_popcountll(__ballot(m < (1u << p)));
+	}
+	unsigned short *out = w.cum + ((long)plane * w.NT + tile) * NCUM;
+	if (lane < NCUM) {
+		int mine = 0;
+#pragma unroll
+		for (int p = 0; p < NCUM; ++p)
+			mine = lane == p ? cnt[p] : mine;
+		out[lane] = (unsigned short)mine;
+	}
+	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
+	for (int o = 32; o; o >>= 1)
+		mx |= __shfl_xor(mx, o);
+	if (lane == 0 && mx)
+		atomicMax(w.planes_dev + plane, ilog2u(mx) + 1);
+}
+
+// ------------------------------------------------------------------ k_plan ---
+
+struct HdrWriter {
+	unsigned *w;
+	long cap_words;
+	unsigned long long acc;
+	int n;
+	long pos;
+	int order;
+	__device__ void put(unsigned v, int nb)
+	{
+		if (nb <= 0)
+			return;
+		acc |= (unsigned long long)(nb < 32 ? v & ((1u << nb) - 1u) : v) << n;
+		n += nb;
+		while (n >= 32) {
+			if (pos < cap_words)
+				w[pos] = (unsigned)acc;
+			++pos;
+			acc >>= 32;
+			n -= 32;
+		}
+	}
+	__device__ void vli(unsigned v)
+	{
+		const int top = vli_top(order, v);
+		put(0, top - order);
+		put(1, 1);
+		put(v + (1u << order) - (1u << top), top);
+		order = vli_next(top);
+	}
+	__device__ unsigned bits() const { return (unsigned)(pos * 32 + n); }
+};
+
+__global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words)
+{
+	if (threadIdx.x)
+		return;
+	const int img = blockIdx.x;
+	ImgInfo &I = w.info[img];
+	int planes[3] = { 0, 0, 0 };
+	int pmax = 0;
+	for (int c = 0; c < g.C; ++c) {
+		planes[c] = w.planes_dev[img * g.C + c];
+		pmax = planes[c] > pmax ? planes[c] : pmax;
+		I.planes[c] = planes[c];
+	}
+	I.pmax = pmax;
+	I.error = pmax > MAX_PLANES ? 1 : 0;
+
+	HdrWriter hw;
+	hw.w = out + img * out_words;
+	hw.cap_words = out_words;
+	hw.acc = 0;
+	hw.n = 0;
+	hw.pos = 0;
+	hw.order = 0;
+	// encode.c:169-172 header bytes
+	hw.put('W', 8);
+	hw.put(g.C == 3 ? '6' : '5', 8);
+	hw.put((unsigned)(g.W - 1) & 0xffffu, 16);
+	hw.put((unsigned)(g.H - 1) & 0xffffu, 16);
+	// encode.c:97-110 root image per channel
+	for (int c = 0; c < g.C; ++c) {
+		const int *r = lin + (long)(img * g.C + c) * g.total;
+		unsigned mx = 0;
+		for (int i = 0; i < g.pixels[0]; ++i) {
+			const int v = r[i];
+			const unsigned a = (unsigned)(v < 0 ? -v : v);
+			mx = a > mx ? a : mx;
+		}
+		const int cnt = mx ? ilog2u(mx) + 1 : 0;
+		hw.vli((unsigned)cnt);
+		if (cnt)
+			for (int i = 0; i < g.pixels[0]; ++i) {
+				const int v = r[i];
+				hw.put((unsigned)(v < 0 ? -v : v), cnt);
+				if (v)
+					hw.put(v < 0, 1);
+			}
+	}
+	I.root_bits = hw.bits() - 48;
+	for (int c = 0; c < g.C; ++c)   // encode.c:181-182
+		hw.vli((unsigned)planes[c]);
+	I.hdr_bits = hw.bits();
+	I.order0 = hw.order;
+	if (hw.n && hw.pos < hw.cap_words)
+		hw.w[hw.pos] = (unsigned)hw.acc;
+
+	// encode.c:183-221 schedule.  A flat image (planes all 0) still codes luma
+	// level 0 at "plane -1" (SURVEY §5.9-2): all symbols are zero, which is what
+	// plane 0 of an all-zero ring yields, so p is clamped to 0 there.
+	int *sd = w.seg_desc + (long)img * MAX_SEGS;
+	int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	int K = 0, E = 0;
+	auto add = [&](int c, int l, int p) {
+		if (K >= MAX_SEGS)
+			return;
+		sd[K] = c | (l << 4) | ((p < 0 ? 0 : p) + 1) << 8;
+		eb[K] = E;
+		E += g.tile_first[l + 1] - g.tile_first[l];
+		++K;
+	};
+	const int levels = g.levels;
+	const int layers_max = 2 * (levels > pmax ? levels : pmax) - 1;
+	if (pmax == planes[0])
+		add(0, 0, planes[0] - 1);
+	for (int layer = 0; layer < layers_max; ++layer) {
+		for (int l = 0; l < levels && l <= layer + 1; ++l) {
+			const int p = pmax - 1 - (layer + 1 - l);
+			if (p >= 0 && p < planes[0])
+				add(0, l, p);
+		}
+		for (int l = 0; l < levels && l <= layer; ++l) {
+			const int p = pmax - 1 - (layer - l);
+			for (int c = 1; c < g.C; ++c)
+				if (p >= 0 && p < planes[c])
+					add(c, l, p);
+		}
+	}
+	eb[K] = E;
+	I.K = K;
+	I.E = E;
+}
+
+// --------------------------------------------------------------- k_entries ---
+
+__device__ __forceinline__ int seg_of_entry(const int *eb, int K, int e)
+{
+	int lo = 0, hi = K - 1;   // largest k with eb[k] <= e
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (eb[mid] <= e)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	return lo;
+}
+
+// block-wide exclusive scan of one unsigned per thread (1024 threads); returns total in `total`
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *wsum, unsigned &total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned t = __shfl_up(inc, o);
+		if (lane >= o)
+			inc += t;
+	}
+	if (lane == 63)
+		wsum[wv] = inc;
+	__syncthreads();
+	unsigned woff = 0, all = 0;
+	for (int k = 0; k < 16; ++k) {
+		const unsigned s = wsum[k];
+		woff += k < wv ? s : 0u;
+		all += s;
+	}
+	__syncthreads();
+	total = all;
+	return woff + inc - v;
+}
+
+constexpr int ENT_PER_THREAD = 4;
+
+__global__ __launch_bounds__(1024) void k_entries(PackGeom g, Work w)
+{
+	__shared__ unsigned wsum[16];
+	const int img = blockIdx.x;
+	ImgInfo &I = w.info[img];
+	const int K = I.K, E = I.E;
+	const int *sd = w.seg_desc + (long)img * MAX_SEGS;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	unsigned short *ones = w.ent_ones + img * w.ES, *zeros = w.ent_zeros + img * w.ES, *refs = w.ent_refs + img * w.ES;
+	unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1);
+	unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+	unsigned tok_run = 0, ref_run = 0;
+	for (int base = 0; base < E; base += 1024 * ENT_PER_THREAD) {
+		unsigned t_loc[ENT_PER_THREAD], r_loc[ENT_PER_THREAD];
+		unsigned tsum = 0, rsum = 0;
+		for (int q = 0; q < ENT_PER_THREAD; ++q) {
+			const int e = base + threadIdx.x * ENT_PER_THREAD + q;
+			unsigned nt = 0, nr = 0;
+			if (e < E) {
+				const int k = seg_of_entry(eb, K, e);
+				int c, l, p;
+				seg_unpack(sd[k], c, l, p);
+				const int j = e - eb[k];
+				const int ntile = g.tile_first[l + 1] - g.tile_first[l];
+				const long ring = (long)g.pixels[l + 1] - g.pixels[l];
+				const long left = ring - (long)j * TILE;
+				const int cnt = left < TILE ? (int)left : TILE;
+				const unsigned short *cum = w.cum + ((long)(img * g.C + c) * w.NT + g.tile_first[l] + j) * NCUM;
+				const int z = cum[p], upto = cum[p + 1];
+				zeros[e] = (unsigned short)z;
+				ones[e] = (unsigned short)(upto - z);
+				refs[e] = (unsigned short)(cnt - upto);
+				nt = (unsigned)(upto - z) + (j == ntile - 1 ? 1u : 0u);   // + the segment's break slot
+				nr = (unsigned)(cnt - upto);
+			}
+			t_loc[q] = tsum;
+			r_loc[q] = rsum;
+			tsum += nt;
+			rsum += nr;
+		}
+		unsigned tt, rt;
+		const unsigned tb = block_excl_scan(tsum, wsum, tt);
+		const unsigned rb = block_excl_scan(rsum, wsum, rt);
+		for (int q = 0; q < ENT_PER_THREAD; ++q) {
+			const int e = base + threadIdx.x * ENT_PER_THREAD + q;
+			if (e < E) {
+				tokbase[e] = tok_run + tb + t_loc[q];
+				refscum[e] = ref_run + rb + r_loc[q];
+			}
+		}
+		tok_run += tt;
+		ref_run += rt;
+	}
+	if (threadIdx.x == 0) {
+		tokbase[E] = tok_run;
+		refscum[E] = ref_run;
+		I.T = tok_run + 1;   // + final flush (encode.c:221)
+	}
+	__syncthreads();
+	__threadfence_block();
+	unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
+	for (int k = threadIdx.x; k < K; k += 1024) {
+		srefs[k] = refscum[eb[k + 1]] - refscum[eb[k]];
+		const int last = eb[k + 1] - 1;
+		btok[k] = tokbase[last] + ones[last];
+	}
+}
+
+// ---------------------------------------------------------------- k_tokens ---
+
+__global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restrict__ lin, Work w)
+{
+	const int lane = threadIdx.x & 63;
+	const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	if (e >= I.E)
+		return;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int k = seg_of_entry(eb, I.K, e);
+	int c, l, p;
+	seg_unpack(w.seg_desc[(long)img * MAX_SEGS + k], c, l, p);
+	const int j = e - eb[k];
+	const long ring1 = g.pixels[l + 1];
+	const long base = g.pixels[l] + (long)j * TILE;
+	const int *src = lin + (long)(img * g.C + c) * g.total;
+	unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
+	unsigned *tok_run = w.tok_run + img * w.TS;
+	unsigned char *tok_flag = w.tok_flag + img * w.TS;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	unsigned pending = 0;   // zeros since the last one of this tile (uniform)
+	for (int r = 0; r < ROWS; ++r) {
+		const long i = base + r * 64 + lane;
+		const bool in = i < ring1;
+		const int v = in ? src[i] : 0;
+		const unsigned m = (unsigned)(v < 0 ? -v : v);
+		const bool refine = in && (m >> (p + 1)) != 0;
+		const bool one = in && !refine && ((m >> p) & 1u);
+		const bool zero = in && !refine && !one;
+		const unsigned long long om = __ballot(one), zm = __ballot(zero);
+		if (one) {
+			const unsigned long long prev = om & below;
+			unsigned run;
+			if (prev) {
+				const int hb = 63 - __builtin_clzll(prev);
+				run = (unsigned)__builtin_popcountll(zm & below & ~((2ull << hb) - 1ull));
+			} else {
+				run = pending + (unsigned)__builtin_popcountll(zm & below);
+			}
+			const unsigned idx = tb + (unsigned)__builtin_popcountll(prev);
+			tok_run[idx] = run;
+			tok_flag[idx] = (unsigned char)(F_HAS_SIGN | (v < 0 ? F_SIGN : 0));
+		}
+		if (om) {
+			const int last = 63 - __builtin_clzll(om);
+			pending = last == 63 ? 0u : (unsigned)__builtin_popcountll(zm >> (last + 1));
+			tb += (unsigned)__builtin_popcountll(om);
+		} else {
+			pending += (unsigned)__builtin_popcountll(zm);
+		}
+	}
+	if (lane == 0)
+		w.ent_tz[img * w.ES + e] = (unsigned short)pending;
+}
+
+// ----------------------------------------------------------------- k_carry ---
+// Pending-run state s across entries: a tile maps s -> (has_one ? tz : s + tz);
+// a segment end with refinement bits emits s as a phantom terminator (if s > 0)
+// and resets it (rle.h:79-89); without refinement bits the run carries on.
+// Maps are (keep, add): s -> add + (keep ? s : 0).
+
+struct RunMap {
+	unsigned keep, add;
+};
+
+__device__ __forceinline__ RunMap compose(RunMap a, RunMap b)   // a then b
+{
+	RunMap r;
+	r.keep = a.keep & b.keep;
+	r.add = b.keep ? a.add + b.add : b.add;
+	return r;
+}
+
+__global__ __launch_bounds__(1024) void k_carry(PackGeom g, Work w)
+{
+	__shared__ RunMap sm[1024];
+	const int img = blockIdx.x;
+	ImgInfo &I = w.info[img];
+	const int K = I.K, E = I.E;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const unsigned short *ones = w.ent_ones + img * w.ES, *tz = w.ent_tz + img * w.ES;
+	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1);
+	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	unsigned *tok_run = w.tok_run + img * w.TS;
+	unsigned char *tok_flag = w.tok_flag + img * w.TS;
+	const int per = (E + 1023) / 1024;
+	const int e0 = threadIdx.x * per, e1 = min(e0 + per, E);
+
+	auto walk = [&](unsigned s, bool apply) {
+		RunMap m = { 1u, 0u };
+		int k = e0 < e1 ? seg_of_entry(eb, K, e0) : 0;
+		for (int e = e0; e < e1; ++e) {
+			while (e >= eb[k + 1])
+				++k;
+			const bool has_one = ones[e] != 0;
+			if (apply && has_one)
+				tok_run[tokbase[e]] += s;
+			RunMap t = { has_one ? 0u : 1u, tz[e] };
+			s = t.add + (t.keep ? s : 0u);
+			m = compose(m, t);
+			if (e == eb[k + 1] - 1) {   // segment end: the break slot
+				const bool refs = srefs[k] != 0;
+				if (apply) {
+					const unsigned idx = tokbase[e] + ones[e];
+					tok_run[idx] = s;
+					tok_flag[idx] = (unsigned char)(F_BREAK | ((refs && s) ? 0u : F_VOID));
+				}
+				if (refs) {
+					RunMap z = { 0u, 0u };
+					m = compose(m, z);
+					s = 0;
+				}
+			}
+		}
+		return apply ? RunMap{ 0u, s } : m;
+	};
+
+	RunMap mine = walk(0, false);
+	sm[threadIdx.x] = mine;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan of maps
+		RunMap a = sm[threadIdx.x];
+		RunMap b = a;
+		if ((int)threadIdx.x >= o)
+			b = compose(sm[threadIdx.x - o], a);
+		__syncthreads();
+		sm[threadIdx.x] = b;
+		__syncthreads();
+	}
+	const unsigned s_in = threadIdx.x ? sm[threadIdx.x - 1].add : 0u;   // state 0 at stream start (rle.h:33)
+	walk(s_in, true);
+	if (threadIdx.x == 1023) {
+		const unsigned s_end = sm[1023].add;
+		tok_run[I.T - 1] = s_end;                 // encode.c:221 rle_flush: always emitted
+		tok_flag[I.T - 1] = (unsigned char)F_FLUSH;
+	}
+}
+
+// ------------------------------------------------------------------- k_lut ---
+// Lanes 0..31 of each half-wave are the 32 possible VLI orders at the start of
+// a 4096-token chunk; the half-wave walks the chunk once and every lane follows
+// its own start state.  Snapshots at every 64-token boundary (sublut) let the
+// next pass start each lane's 64 tokens from the right order.
+
+__device__ __forceinline__ int vli_step(int o, unsigned v, bool skip)
+{
+	const int nx = vli_next(vli_top(o, v));
+	return skip ? o : nx;
+}
+
+__global__ __launch_bounds__(256) void k_lut(Work w)
+{
+	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+	const long chunk = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+	const int img = blockIdx.y;
+	const unsigned T = w.info[img].T;
+	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
+	// both halves must stay in the loop together for the shuffles
+	const bool live = chunk < nchunks;
+	const long wave_first = chunk - half;
+	if (wave_first >= nchunks)
+		return;
+	const unsigned *run = w.tok_run + img * w.TS;
+	const unsigned char *flag = w.tok_flag + img * w.TS;
+	unsigned char *sub = w.sublut + (img * w.NCS + chunk) * 64 * 32;
+	int o = s;
+	for (int q = 0; q < 64; ++q) {
+		if (live)
+			sub[q * 32 + s] = (unsigned char)o;
+		const long t0 = chunk * CHUNK + q * SUB;
+		// each lane of the half holds two consecutive tokens
+		const long ta = t0 + 2 * s, tb = ta + 1;
+		const unsigned va = live && ta < T ? run[ta] : 0u, vb = live && tb < T ? run[tb] : 0u;
+		const unsigned fa = live && ta < T ? flag[ta] : F_VOID, fb = live && tb < T ? flag[tb] : F_VOID;
+#pragma unroll 8
+		for (int t = 0; t < 32; ++t) {
+			const int srcl = half * 32 + t;
+			const unsigned v0 = __shfl(va, srcl), v1 = __shfl(vb, srcl);
+			const unsigned f0 = __shfl(fa, srcl), f1 = __shfl(fb, srcl);
+			o = vli_step(o, v0, f0 & F_VOID);
+			o = vli_step(o, v1, f1 & F_VOID);
+		}
+	}
+	if (live)
+		w.lut[(img * w.NCS + chunk) * 32 + s] = (unsigned char)o;
+}
+
+// group maps: 32 lanes (states) walk the 64 chunk maps of a group
+__global__ __launch_bounds__(256) void k_chain_groups(Work w)
+{
+	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+	const long group = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+	const int img = blockIdx.y;
+	const unsigned T = w.info[img].T;
+	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
+	const long ngroups = (nchunks + GROUP - 1) / GROUP;
+	if (group >= ngroups)
+		return;
+	const unsigned char *lut = w.lut + img * w.NCS * 32;
+	int o = s;
+	for (long c = group * GROUP; c < min((group + 1) * GROUP, nchunks); ++c)
+		o = lut[c * 32 + o];
+	w.glut[(img * w.NGS + group) * 32 + s] = (unsigned char)o;
+}
+
+// per image: serial over groups, then every group's chunks in parallel
+__global__ __launch_bounds__(1024) void k_chain_image(Work w)
+{
+	const int img = blockIdx.x;
+	const ImgInfo &I = w.info[img];
+	const long nchunks = ((long)I.T + CHUNK - 1) / CHUNK;
+	const long ngroups = (nchunks + GROUP - 1) / GROUP;
+	unsigned char *gentry = w.group_entry + img * w.NGS;
+	if (threadIdx.x == 0) {
+		int o = I.order0;
+		for (long gq = 0; gq < ngroups; ++gq) {
+			gentry[gq] = (unsigned char)o;
+			o = w.glut[(img * w.NGS + gq) * 32 + o];
+		}
+	}
+	__syncthreads();
+	__threadfence_block();
+	const unsigned char *lut = w.lut + img * w.NCS * 32;
+	unsigned char *centry = w.chunk_entry + img * w.NCS;
+	for (long gq = threadIdx.x; gq < ngroups; gq += 1024) {
+		int o = gentry[gq];
+		for (long c = gq * GROUP; c < min((gq + 1) * GROUP, nchunks); ++c) {
+			centry[c] = (unsigned char)o;
+			o = lut[c * 32 + o];
+		}
+	}
+}
+
+// ---------------------------------------------------------------- k_orders ---
+// One lane per 64 tokens, now with the true start order: record each token's
+// order and the bits it will occupy; wave-scan the lane totals.
+
+__device__ __forceinline__ long find_break_seg(const unsigned *btok, int K, unsigned t)
+{
+	int lo = 0, hi = K - 1;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (btok[mid] < t)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long long v, unsigned long long &total)
+{
+	const int lane = lane_id();
+	unsigned long long inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned long long t = __shfl_up(inc, o);
+		if (lane >= o)
+			inc += t;
+	}
+	total = __shfl(inc, 63);
+	return inc - v;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_orders(Work w, unsigned *out, long out_words)
+{
+	const int lane = threadIdx.x & 63;
+	const long chunk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const unsigned T = I.T;
+	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
+	if (chunk >= nchunks)
+		return;
+	const unsigned *run = w.tok_run + img * w.TS;
+	const unsigned char *flag = w.tok_flag + img * w.TS;
+	unsigned char *ord = w.tok_ord + img * w.TS;
+	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
+	unsigned long long *rawoff = w.seg_rawoff + (long)img * MAX_SEGS;
+	const long t0 = chunk * CHUNK + (long)lane * SUB;
+	const long t1 = min(t0 + SUB, (long)T);
+
+	unsigned long long bits = 0;
+	if (!EMIT) {
+		int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
+		for (long t = t0; t < t1; ++t) {
+			const unsigned f = flag[t];
+			ord[t] = (unsigned char)o;
+			if (!(f & F_VOID)) {
+				const int top = vli_top(o, run[t]);
+				bits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
+				o = vli_next(top);
+			}
+			if (f & F_BREAK)
+				bits += srefs[find_break_seg(btok, I.K, (unsigned)t)];
+		}
+		unsigned long long total;
+		wave_excl_scan64(bits, total);
+		if (lane == 0)
+			w.chunk_bits[img * w.NCS + chunk] = total;
+		return;
+	}
+
+	// EMIT: recompute this lane's bit count to find its start offset
+	for (long t = t0; t < t1; ++t) {
+		const unsigned f = flag[t];
+		if (!(f & F_VOID)) {
+			const int o = ord[t];
+			const int top = vli_top(o, run[t]);
+			bits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
+		}
+		if (f & F_BREAK)
+			bits += srefs[find_break_seg(btok, I.K, (unsigned)t)];
+	}
+	unsigned long long total;
+	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + wave_excl_scan64(bits, total);
+
+	// bits.h:58-78 LSB-first writer over this lane's contiguous bit range
+	unsigned *dst = out + img * out_words;
+	unsigned long long acc = 0;      // bits [wordpos*32, ...) being assembled
+	long wordpos = (long)(pos >> 5);
+	int fill = (int)(pos & 31);      // valid low bits of acc are [fill_start..): acc holds bits at offset within word
+	auto flush_word = [&]() {
+		if (wordpos < out_words && (unsigned)acc)
+			atomicOr(dst + wordpos, (unsigned)acc);
+		acc >>= 32;
+		++wordpos;
+		fill -= 32;
+	};
+	auto put = [&](unsigned v, int nb) {   // nb <= 32
+		if (nb <= 0)
+			return;
+		acc |= (unsigned long long)(nb < 32 ? v & ((1u << nb) - 1u) : v) << fill;
+		fill += nb;
+		if (fill >= 32)
+			flush_word();
+	};
+	for (long t = t0; t < t1; ++t) {
+		const unsigned f = flag[t];
+		if (!(f & F_VOID)) {
+			const int o = ord[t];
+			const unsigned v = run[t];
+			const int top = vli_top(o, v);
+			put(0, top - o);
+			put(1, 1);
+			put(v + (1u << o) - (1u << top), top);
+			if (f & F_HAS_SIGN)
+				put(f & F_SIGN, 1);
+		}
+		if (f & F_BREAK) {
+			const long k = find_break_seg(btok, I.K, (unsigned)t);
+			const unsigned long long here = ((unsigned long long)wordpos << 5) + (unsigned)fill;
+			rawoff[k] = here;
+			const unsigned n2 = srefs[k];
+			if (n2) {   // skip the refinement block (k_refine fills it)
+				if (fill && wordpos < out_words && (unsigned)acc)
+					atomicOr(dst + wordpos, (unsigned)acc);
+				const unsigned long long next = here + n2;
+				acc = 0;
+				wordpos = (long)(next >> 5);
+				fill = (int)(next & 31);
+			}
+		}
+	}
+	if (fill && wordpos < out_words && (unsigned)acc)
+		atomicOr(dst + wordpos, (unsigned)acc);
+}
+
+// per image: exclusive scan of chunk bit totals
+__global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
+{
+	__shared__ unsigned long long wsum[16];
+	__shared__ unsigned long long carry;
+	const int img = blockIdx.x;
+	ImgInfo &I = w.info[img];
+	const long nchunks = ((long)I.T + CHUNK - 1) / CHUNK;
+	const unsigned long long *cb = w.chunk_bits + img * w.NCS;
+	unsigned long long *base = w.chunk_base + img * w.NCS;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (threadIdx.x == 0)
+		carry = I.hdr_bits;
+	__syncthreads();
+	for (long b0 = 0; b0 < nchunks; b0 += 1024) {
+		const long i = b0 + threadIdx.x;
+		const unsigned long long v = i < nchunks ? cb[i] : 0ull;
+		unsigned long long inc = v;
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned long long t = __shfl_up(inc, o);
+			if (lane >= o)
+				inc += t;
+		}
+		if (lane == 63)
+			wsum[wv] = inc;
+		__syncthreads();
+		unsigned long long woff = 0, all = 0;
+		for (int k = 0; k < 16; ++k) {
+			const unsigned long long s = wsum[k];
+			woff += k < wv ? s : 0ull;
+			all += s;
+		}
+		const unsigned long long c = carry;
+		if (i < nchunks)
+			base[i] = c + woff + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 0)
+			carry = c + all;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const unsigned long long bits = carry;
+		unsigned long long bytes = (bits + 7) >> 3;
+		// bytes.h:75-78: nothing is written past `capacity` bytes; the stream is a prefix
+		I.total_bits = bits;
+		if (capacity > 0 && bytes > (unsigned long long)capacity) {
+			bytes = (unsigned long long)capacity;
+			// the encoder only notices the limit when a complete byte is refused
+			// (bits.h:61-66); a refused final padding byte (bits.h:51-56) leaves the count alone
+			if (bits >= 8ull * ((unsigned long long)capacity + 1))
+				I.total_bits = bytes * 8;
+		}
+		I.nbytes = bytes;
+	}
+}
+
+// ---------------------------------------------------------------- k_refine ---
+// encode.c:84-93 second pass: raw magnitude bits of already-significant
+// coefficients, in coefficient order.  The k-th refinement coefficient of the
+// segment owns bit (segment block offset + k).
+
+__global__ __launch_bounds__(256) void k_refine(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words)
+{
+	__shared__ unsigned stage[4][TILE / 32 + 2];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int e = blockIdx.x * 4 + wv;
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	if (e >= I.E)
+		return;
+	const unsigned nref = w.ent_refs[img * w.ES + e];
+	if (!nref)
+		return;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int k = seg_of_entry(eb, I.K, e);
+	int c, l, p;
+	seg_unpack(w.seg_desc[(long)img * MAX_SEGS + k], c, l, p);
+	const int j = e - eb[k];
+	const long ring1 = g.pixels[l + 1];
+	const long base = g.pixels[l] + (long)j * TILE;
+	const int *src = lin + (long)(img * g.C + c) * g.total;
+	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+	const unsigned long long bit0 = w.seg_rawoff[(long)img * MAX_SEGS + k] + (refscum[e] - refscum[eb[k]]);
+	unsigned *st = stage[wv];
+	if (lane < TILE / 32 + 2)
+		st[lane] = 0;
+	// each wave only touches its own stage row; wave-level ordering suffices
+	__builtin_amdgcn_wave_barrier();
+	const int shift = (int)(bit0 & 31);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	unsigned done = 0;
+	for (int r = 0; r < ROWS; ++r) {
+		const long i = base + r * 64 + lane;
+		const bool in = i < ring1;
+		const int v = in ? src[i] : 0;
+		const unsigned m = (unsigned)(v < 0 ? -v : v);
+		const bool refine = in && (m >> (p + 1)) != 0;
+		const unsigned long long rm = __ballot(refine);
+		if (refine && ((m >> p) & 1u)) {
+			const unsigned pos = (unsigned)shift + done + (unsigned)__builtin_popcountll(rm & below);
+			atomicOr(&st[pos >> 5], 1u << (pos & 31));
+		}
+		done += (unsigned)__builtin_popcountll(rm);
+	}
+	__builtin_amdgcn_wave_barrier();
+	__threadfence_block();
+	unsigned *dst = out + img * out_words;
+	const long w0 = (long)(bit0 >> 5);
+	const int nwords = (int)((shift + nref + 31) >> 5);
+	if (lane < nwords) {
+		const unsigned val = st[lane];
+		if (val && w0 + lane < out_words)
+			atomicOr(dst + w0 + lane, val);
+	}
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ driver ---
+
+enum {
+	SLOT_PK_CUM = 2, SLOT_PK_SMALL, SLOT_PK_ENT, SLOT_PK_TOKRUN, SLOT_PK_TOKB, SLOT_PK_LUT, SLOT_PK_CHUNK,
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int H, int C, int n, long capacity,
+	uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
+{
+	if (!ctx || !lin || !out || !dev_info || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || W > 65536 || H > 65536 ||
+		(C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
+		return DWTX_ERR_ARG;
+	PackGeom g;
+	{
+		int lengths[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS];
+		g.levels = dwtx_compute_lengths(lengths, pixels, widths, heights, W, H, DWTX_MIN_LEN);
+		for (int l = 0; l <= g.levels; ++l)
+			g.pixels[l] = pixels[l];
+	}
+	g.C = C;
+	g.W = W;
+	g.H = H;
+	g.total = (long)W * H;
+	int NT = 0;
+	for (int l = 0; l < g.levels; ++l) {
+		g.tile_first[l] = NT;
+		NT += (int)(((long)g.pixels[l + 1] - g.pixels[l] + TILE - 1) / TILE);
+	}
+	g.tile_first[g.levels] = NT;
+
+	Work w;
+	memset(&w, 0, sizeof(w));
+	w.NT = NT;
+	w.ES = (long)NT * C * MAX_PLANES + 16;
+	w.TS = (long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8;
+	w.NCS = (w.TS + CHUNK - 1) / CHUNK;
+	w.NGS = (w.NCS + GROUP - 1) / GROUP;
+	const int nplanes = n * C;
+
+	// carve scratch
+	{
+		size_t b = sizeof(unsigned short) * (size_t)nplanes * NT * NCUM;
+		w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b);
+		size_t off = 0;
+		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+		const size_t o_planes = take(sizeof(int) * nplanes);
+		const size_t o_info = take(sizeof(ImgInfo) * n);
+		const size_t o_sd = take(sizeof(int) * (size_t)n * MAX_SEGS);
+		const size_t o_eb = take(sizeof(int) * (size_t)n * (MAX_SEGS + 1));
+		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
+		const size_t o_ro = take(sizeof(unsigned long long) * (size_t)n * MAX_SEGS);
+		const size_t o_bt = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
+		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
+		if (!w.cum || !small)
+			return DWTX_ERR_NOMEM;
+		w.planes_dev = (int *)(small + o_planes);
+		w.info = (ImgInfo *)(small + o_info);
+		w.seg_desc = (int *)(small + o_sd);
+		w.seg_ebase = (int *)(small + o_eb);
+		w.seg_refs = (unsigned *)(small + o_sr);
+		w.seg_rawoff = (unsigned long long *)(small + o_ro);
+		w.brk_tok = (unsigned *)(small + o_bt);
+		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
+
+		off = 0;
+		const size_t o_on = take(sizeof(short) * (size_t)n * w.ES);
+		const size_t o_ze = take(sizeof(short) * (size_t)n * w.ES);
+		const size_t o_re = take(sizeof(short) * (size_t)n * w.ES);
+		const size_t o_tz = take(sizeof(short) * (size_t)n * w.ES);
+		const size_t o_tb = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
+		const size_t o_rc = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
+		char *ent = (char *)dwtx_scratch(ctx, SLOT_PK_ENT, off);
+		if (!ent)
+			return DWTX_ERR_NOMEM;
+		w.ent_ones = (unsigned short *)(ent + o_on);
+		w.ent_zeros = (unsigned short *)(ent + o_ze);
+		w.ent_refs = (unsigned short *)(ent + o_re);
+		w.ent_tz = (unsigned short *)(ent + o_tz);
+		w.ent_tokbase = (unsigned *)(ent + o_tb);
+		w.ent_refscum = (unsigned *)(ent + o_rc);
+
+		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
+		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 2 * (size_t)n * w.TS);
+		if (!w.tok_run || !tb)
+			return DWTX_ERR_NOMEM;
+		w.tok_flag = (unsigned char *)tb;
+		w.tok_ord = (unsigned char *)tb + (size_t)n * w.TS;
+
+		w.sublut = (unsigned char *)dwtx_scratch(ctx, SLOT_PK_LUT, (size_t)n * w.NCS * 64 * 32);
+		off = 0;
+		const size_t o_lut = take((size_t)n * w.NCS * 32);
+		const size_t o_gl = take((size_t)n * w.NGS * 32);
+		const size_t o_ce = take((size_t)n * w.NCS);
+		const size_t o_ge = take((size_t)n * w.NGS);
+		const size_t o_cb = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
+		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
+		char *ch = (char *)dwtx_scratch(ctx, SLOT_PK_CHUNK, off);
+		if (!w.sublut || !ch)
+			return DWTX_ERR_NOMEM;
+		w.lut = (unsigned char *)(ch + o_lut);
+		w.glut = (unsigned char *)(ch + o_gl);
+		w.chunk_entry = (unsigned char *)(ch + o_ce);
+		w.group_entry = (unsigned char *)(ch + o_ge);
+		w.chunk_bits = (unsigned long long *)(ch + o_cb);
+		w.chunk_base = (unsigned long long *)(ch + o_cs);
+	}
+
+	hipStream_t s = ctx->stream;
+	const long out_words = (long)(out_stride / 4);
+	unsigned *outw = (unsigned *)out;
+	DWTX_HIP(hipMemsetAsync(out, 0, out_stride * (size_t)n, s));
+
+	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
+	hipLaunchKernelGGL(k_entries, dim3(n), dim3(1024), 0, s, g, w);
+	const int egrid = (int)((w.ES + 3) / 4);
+	hipLaunchKernelGGL(k_tokens, dim3(egrid, n), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_carry, dim3(n), dim3(1024), 0, s, g, w);
+	hipLaunchKernelGGL(k_lut, dim3((int)((w.NCS + 7) / 8), n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
+	const int cgrid = (int)((w.NCS + 3) / 4);
+	hipLaunchKernelGGL(k_orders<false>, dim3(cgrid, n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
+	hipLaunchKernelGGL(k_orders<true>, dim3(cgrid, n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_refine, dim3(egrid, n), dim3(256), 0, s, g, lin, w, outw, out_words);
+	DWTX_LAUNCH_CHECK();
+	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
+	DWTX_HIP(hipMemcpyAsync(dev_info, w.info, sizeof(ImgInfo) * (size_t)n, hipMemcpyDeviceToDevice, s));
+	return DWTX_OK;
+}

@@ -62,6 +62,22 @@ typedef struct dwtx_stats {
 	int planes[3];
 } dwtx_stats;
 
+/* Per-image result record of the entropy stage (device or host memory). */
+typedef struct dwtx_stream_info {
+	int planes[3];                 /* encode.c:163-165 */
+	int pmax;
+	int segments;                  /* (channel, level, plane) segments in the schedule, encode.c:183-221 */
+	int entries;
+	unsigned tokens;               /* VLI token slots (incl. void ones) */
+	int order0;                    /* VLI order after header, root image and plane counts */
+	unsigned hdr_bits;             /* 48 header bits + root image + plane counts */
+	unsigned root_bits;            /* encode.c:179-180 */
+	unsigned long long total_bits; /* encode.c:226: bit count before padding (8*capacity when truncated) */
+	unsigned long long nbytes;     /* bytes of the .dwt stream: min(capacity, ceil(total_bits/8)) */
+	int error;                     /* non-zero: unsupported data (more than 16 bit planes) */
+	int pad;
+} dwtx_stream_info;
+
 /* ---- context / memory ---------------------------------------------------- */
 
 /* Create a context on HIP device `device` with a stream of its own. */
@@ -110,6 +126,16 @@ int dwtx_linearization(dwtx_ctx *ctx, int32_t *dev_lin, const int32_t *dev_pyr, 
  * bias, decode.c:51-58). */
 int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *dev_pyr, const int32_t *dev_lin, const int *dev_missing,
 	int levels_out, int W, int H, int C, int n);
+
+/* encode.c:166-221: header, root image, plane counts, bit-plane segments in
+ * schedule order, final run flush — for n images at once.  dev_lin is the
+ * output of dwtx_linearization ([n*C][W*H], two's complement).  Image i's
+ * stream is written to dev_out + i*out_stride (out_stride a multiple of 4; at
+ * most out_stride bytes are ever written, so it should be >= capacity when
+ * capacity > 0).  capacity <= 0 means unlimited (encode.c:150-152).
+ * dev_info[i].nbytes is the length of stream i. */
+int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *dev_lin, int W, int H, int C, int n, long capacity,
+	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info);
 
 #ifdef __cplusplus
 }

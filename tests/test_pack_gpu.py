@@ -1,0 +1,83 @@
+"""GPU parity: the encoder's entropy stage (dwtx_encode_planes) vs the oracle's .dwt bytes."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 8, 1), (8, 9, 3), (15, 15, 3), (16, 16, 1), (53, 37, 3), (77, 131, 3), (300, 17, 1), (17, 300, 3),
+          (255, 257, 1), (64, 64, 3), (240, 320, 3), (512, 512, 1), (360, 640, 3)]
+
+
+def lin_of(pix):
+    _, lin, planes = orc.stage_dump(pix)
+    return lin, planes
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_stream_matches_oracle(ctx, shape, kind):
+    import torch
+
+    H, W, Cn = shape
+    pix = orc.synth(W, H, Cn, 21, kind)
+    lin, planes = lin_of(pix)
+    want, st = orc.encode(pix)
+    streams, infos = ctx.encode_planes(torch.from_numpy(lin).cuda(), W, H, Cn)
+    assert list(infos[0].planes)[:Cn] == planes
+    assert infos[0].root_bits == st.root_bits
+    assert infos[0].total_bits == st.total_bits
+    assert len(streams[0]) == len(want)
+    assert streams[0] == want
+
+
+def test_smpte_stream(ctx):
+    import torch
+
+    pix = orc.read_pnm(orc.GOLDEN + "/smpte.pnm")
+    lin, _ = lin_of(pix)
+    streams, infos = ctx.encode_planes(torch.from_numpy(lin).cuda(), 320, 240, 3)
+    assert streams[0] == open(orc.GOLDEN + "/smpte.dwt", "rb").read()
+    assert (infos[0].hdr_bits, infos[0].root_bits, infos[0].total_bits) == (48 + 559 + infos[0].hdr_bits - 48 - 559, 559, 81174)
+
+
+def test_batch_of_different_images(ctx):
+    import torch
+
+    W, H, Cn, n = 131, 77, 3, 6
+    pixs = [orc.synth(W, H, Cn, 100 + i, i & 1) for i in range(n)]
+    pixs[3] = np.full((H, W, Cn), 90, dtype=np.uint8)          # flat image quirk
+    lins = np.concatenate([lin_of(p)[0] for p in pixs])
+    streams, _ = ctx.encode_planes(torch.from_numpy(lins).cuda(), W, H, Cn)
+    for p, s in zip(pixs, streams):
+        assert s == orc.encode(p)[0]
+
+
+@pytest.mark.parametrize("cap", [1, 5, 6, 7, 33, 100, 1000, 4096, 14553, 14554, 14555, 100000])
+def test_capacity_is_prefix(ctx, cap):
+    import torch
+
+    pix = orc.synth(131, 77, 3, 5, 0)
+    lin, _ = lin_of(pix)
+    want, st = orc.encode(pix, cap)
+    streams, infos = ctx.encode_planes(torch.from_numpy(lin).cuda(), 131, 77, 3, capacity=cap)
+    assert streams[0] == want
+    if cap >= 200:   # below that the oracle's cosmetic bit counter is inside the root coder
+        assert infos[0].total_bits == st.total_bits
+
+
+def test_1080p_rgb_and_4096_gray(ctx):
+    import hashlib
+    import json
+    import os
+    import torch
+
+    G = json.load(open(os.path.join(orc.GOLDEN, "golden.json")))
+    for name in ("c1920x1080", "g4096x4096"):
+        rec = G[name]
+        pix = orc.synth(rec["W"], rec["H"], rec["C"], rec["seed"], rec["kind"])
+        lin, _ = lin_of(pix)
+        streams, _ = ctx.encode_planes(torch.from_numpy(lin).cuda(), rec["W"], rec["H"], rec["C"])
+        assert len(streams[0]) == rec["dwt_len"]
+        assert hashlib.sha256(streams[0]).hexdigest() == rec["dwt_sha256"]
