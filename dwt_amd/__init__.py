@@ -10,7 +10,7 @@ raise.
 import ctypes as C
 
 from . import _lib
-from ._lib import Geom, Stats, StreamInfo, LIB_PATH  # noqa: F401
+from ._lib import Geom, Stats, StreamInfo, DecodeInfo, LIB_PATH  # noqa: F401
 
 __all__ = ["Context", "DwtxError", "compute_lengths", "geometry", "Geom", "Stats"]
 
@@ -168,3 +168,23 @@ class Context:
                 raise DwtxError(-2, "dwtx_encode_planes (out_stride too small)")
             streams.append(host[i, : infos[i].nbytes].tobytes())
         return streams, infos
+
+    def decode_planes(self, streams, W, H, C_, levels_max=-1):
+        """decode.c:174-250 on a list of .dwt byte strings of one geometry ->
+        (lin int32 [n*C, W*H] two's complement, list of DecodeInfo)."""
+        import numpy as np
+
+        torch = self.torch
+        n = len(streams)
+        stride = (max(len(s) for s in streams) + 64 + 7) // 8 * 8
+        host = np.zeros((n, stride), dtype=np.uint8)
+        for i, s in enumerate(streams):
+            host[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+        dev = torch.from_numpy(host).to(self.device)
+        lens = torch.tensor([len(s) for s in streams], dtype=torch.int64, device=self.device)
+        lin = torch.empty((n * C_, W * H), dtype=torch.int32, device=self.device)
+        infos = (DecodeInfo * n)()
+        _check(self.lib.dwtx_decode_planes(self.h, _ptr(lin), _ptr(dev), stride, _ptr(lens), W, H, C_, n, levels_max,
+                                           C.cast(infos, C.c_void_p)), "dwtx_decode_planes")
+        self._keep = (dev, lens)   # kernels after the internal sync still read the streams
+        return lin, list(infos)

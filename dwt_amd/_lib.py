@@ -31,6 +31,14 @@ class StreamInfo(C.Structure):
     ]
 
 
+class DecodeInfo(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("levels", C.c_int),
+        ("planes", C.c_int * 3), ("pmax", C.c_int), ("level", C.c_int), ("nsegs", C.c_int),
+        ("truncated", C.c_int), ("missing", C.c_int * 48), ("bits_used", C.c_ulonglong),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("meta_bits", C.c_int),
@@ -63,6 +71,7 @@ SYMBOLS = {
     "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_linearization": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_reconstruction": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "dwtx_decode_planes": (_i, [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp]),
     "dwtx_encode_planes": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp]),
 }
 

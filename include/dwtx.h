@@ -78,6 +78,20 @@ typedef struct dwtx_stream_info {
 	int pad;
 } dwtx_stream_info;
 
+/* Per-image result record of the decoder's entropy stage (host memory). */
+typedef struct dwtx_decode_info {
+	int status;                    /* 0 ok; 1 = header, root image or plane counts unreadable (decode.c exits 1) */
+	int W, H, C;
+	int levels;
+	int planes[3];                 /* decode.c:183-186 */
+	int pmax;
+	int level;                     /* finest level any segment touched (decode.c:197,203,219,236); -1 = none */
+	int nsegs;
+	int truncated;                 /* the walk stopped early (end of data or PIXELS cap) */
+	int missing[48];               /* decode.c:193-196: planes not fully decoded, [channel*16 + level] */
+	unsigned long long bits_used;
+} dwtx_decode_info;
+
 /* ---- context / memory ---------------------------------------------------- */
 
 /* Create a context on HIP device `device` with a stream of its own. */
@@ -136,6 +150,17 @@ int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *dev_pyr, const int32_t *dev_lin,
  * dev_info[i].nbytes is the length of stream i. */
 int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *dev_lin, int W, int H, int C, int n, long capacity,
 	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info);
+
+/* decode.c:174-250: root image, plane counts and all bit-plane segments of n
+ * streams of identical geometry (W, H, C as in their headers) into linearised
+ * two's-complement planes dev_lin [n*C][W*H] (zero where the stream ended
+ * early).  Stream i occupies dev_streams + i*stream_stride (stride a multiple
+ * of 8), its byte length is dev_lens[i].  levels_max < 0 = all levels
+ * (decode.c:163-171 computes it from the PIXELS argument).  Synchronous:
+ * host_info[i] is filled on return (level and missing[] drive
+ * dwtx_reconstruction / dwtx_transformation_inv). */
+int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *dev_lin, const uint8_t *dev_streams, size_t stream_stride,
+	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info);
 
 #ifdef __cplusplus
 }

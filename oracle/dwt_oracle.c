@@ -724,9 +724,12 @@ static int get_plane(source *s, uint32_t *v, int num, int plane)
 	return 0;
 }
 
-/* decode.c:136-268 minus file I/O */
-int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
-	uint8_t **pix, int *Wo, int *Ho, int *Co)
+/* decode.c:136-250: everything up to (and including) process().  On success
+ * buf[c] (calloc'ed, g->pixels[levels_max] ints each) holds two's-complement
+ * linearised coefficients, *level the finest level touched, missing[] the
+ * per-(channel,level) count of planes not fully decoded. */
+static int decode_entropy(const uint8_t *dwt, size_t len, long pixels_max,
+	orc_geom *g, int *Cout, int **buf, int *level_out, int *missing, int *planes)
 {
 	if (len < 6 || dwt[0] != 'W' || (dwt[1] != '5' && dwt[1] != '6'))
 		return 1;                                              /* decode.c:145-156 */
@@ -735,25 +738,24 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 	int H = (dwt[4] | (dwt[5] << 8)) + 1;
 	if (W < 8 || H < 8)
 		return 1;
-	orc_geom g;
-	int levels = orc_geometry(&g, W, H, 8);
+	int levels = orc_geometry(g, W, H, 8);
 	int levels_max = levels;
 	if (pixels_max >= 0)                                       /* decode.c:165-171 */
-		while (levels_max > 0 && g.pixels[levels_max] > pixels_max)
+		while (levels_max > 0 && g->pixels[levels_max] > pixels_max)
 			--levels_max;
-	size_t total = (size_t)g.pixels[levels_max];
+	size_t total = (size_t)g->pixels[levels_max];
 	source s;
 	memset(&s, 0, sizeof(s));
 	s.p = dwt;
 	s.len = len;
 	s.pos = 6;
-	int *buf[3] = { 0, 0, 0 };
+	for (int c = 0; c < 3; ++c)
+		buf[c] = 0;
 	for (int c = 0; c < C; ++c)
 		buf[c] = calloc(total, sizeof(int));
-	int rc = 1;
-	int planes[3] = { 0, 0, 0 };
+	planes[0] = planes[1] = planes[2] = 0;
 	for (int c = 0; c < C; ++c)                                /* decode.c:180-182 */
-		if (get_root(&s, buf[c], g.pixels[0]))
+		if (get_root(&s, buf[c], g->pixels[0]))
 			goto fail;
 	for (int c = 0; c < C; ++c)                                /* decode.c:183-186 */
 		if ((planes[c] = src_vli(&s)) < 0)
@@ -763,8 +765,7 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 		if (planes[c] > pmax)
 			pmax = planes[c];
 	int layers_max = 2 * (levels > pmax ? levels : pmax) - 1;
-	int missing[3 * 16];
-	memset(missing, 0, sizeof(missing));
+	memset(missing, 0, sizeof(int) * 48);
 	for (int c = 0; c < C; ++c)
 		for (int l = 0; l < levels; ++l)
 			missing[c * 16 + l] = planes[c];
@@ -772,7 +773,7 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 	int stop = levels_max == 0;                                /* decode.c:199-200 */
 	if (!stop && pmax == planes[0]) {                          /* decode.c:201-207 */
 		level = 0;
-		if (get_plane(&s, (uint32_t *)buf[0] + g.pixels[0], g.pixels[1] - g.pixels[0], planes[0] - 1))
+		if (get_plane(&s, (uint32_t *)buf[0] + g->pixels[0], g->pixels[1] - g->pixels[0], planes[0] - 1))
 			stop = 1;
 		else
 			--missing[0];
@@ -788,7 +789,7 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 				continue;
 			if (level < l)
 				level = l;
-			if (get_plane(&s, (uint32_t *)buf[0] + g.pixels[l], g.pixels[l + 1] - g.pixels[l], p))
+			if (get_plane(&s, (uint32_t *)buf[0] + g->pixels[l], g->pixels[l + 1] - g->pixels[l], p))
 				stop = 1;
 			else
 				--missing[l];
@@ -804,7 +805,7 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 					continue;
 				if (level < l)
 					level = l;
-				if (get_plane(&s, (uint32_t *)buf[c] + g.pixels[l], g.pixels[l + 1] - g.pixels[l], p))
+				if (get_plane(&s, (uint32_t *)buf[c] + g->pixels[l], g->pixels[l + 1] - g->pixels[l], p))
 					stop = 1;
 				else
 					--missing[c * 16 + l];
@@ -814,11 +815,44 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 	/* decode.c:249-250 process(): sign-magnitude -> two's complement on what was touched */
 	for (int c = 0; c < C; ++c) {
 		uint32_t *v = (uint32_t *)buf[c];
-		for (int i = g.pixels[0]; i < g.pixels[level + 1]; ++i) {
+		for (int i = g->pixels[0]; i < g->pixels[level + 1]; ++i) {
 			int mag = (int)(v[i] & 0x1fffffffu);
 			buf[c][i] = (v[i] >> 31) ? -mag : mag;
 		}
 	}
+	*level_out = level;
+	*Cout = C;
+	return 0;
+fail:
+	for (int c = 0; c < C; ++c)
+		free(buf[c]);
+	return 1;
+}
+
+/* entropy stage only: lin is int[C][W*H] (zero-filled beyond what was decoded) */
+int orc_decode_stage(const uint8_t *dwt, size_t len, long pixels_max, int *lin, int *level, int *missing, int *planes)
+{
+	orc_geom g;
+	int C, *buf[3];
+	if (decode_entropy(dwt, len, pixels_max, &g, &C, buf, level, missing, planes))
+		return 1;
+	size_t total = (size_t)g.pixels[g.levels];
+	memset(lin, 0, sizeof(int) * total * C);
+	for (int c = 0; c < C; ++c) {
+		memcpy(lin + c * total, buf[c], sizeof(int) * (size_t)g.pixels[*level + 1]);
+		free(buf[c]);
+	}
+	return 0;
+}
+
+/* decode.c:136-268 minus file I/O */
+int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
+	uint8_t **pix, int *Wo, int *Ho, int *Co)
+{
+	orc_geom g;
+	int C, *buf[3], level, missing[48], planes[3];
+	if (decode_entropy(dwt, len, pixels_max, &g, &C, buf, &level, missing, planes))
+		return 1;
 	int out_levels = level + 1;                                /* decode.c:251-254 */
 	int ow = g.widths[out_levels], oh = g.heights[out_levels];
 	size_t on = (size_t)ow * oh;
@@ -831,15 +865,13 @@ int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 	for (size_t i = 0; i < on * C; ++i)
 		o[i] = (uint8_t)clampi(img[i], 0, 255);                /* pnm.h:108 */
 	free(img);
+	for (int c = 0; c < C; ++c)
+		free(buf[c]);
 	*pix = o;
 	*Wo = ow;
 	*Ho = oh;
 	*Co = C;
-	rc = 0;
-fail:
-	for (int c = 0; c < C; ++c)
-		free(buf[c]);
-	return rc;
+	return 0;
 }
 
 /* ---------------------------------------------------------------- synthetic */

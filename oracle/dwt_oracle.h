@@ -77,6 +77,11 @@ int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 int orc_decode(const uint8_t *dwt, size_t len, long pixels_max,
 	uint8_t **pix, int *W, int *H, int *C);
 
+/* Entropy stage of the decoder only (decode.c:174-250): lin = int[C][W*H]
+ * two's complement, zero beyond what the stream covered; *level = finest level
+ * touched (-1 none); missing = int[48] ([c*16+l]); planes = int[3]. */
+int orc_decode_stage(const uint8_t *dwt, size_t len, long pixels_max, int *lin, int *level, int *missing, int *planes);
+
 /* Stage dumps used by the per-kernel parity tests.
  * coef: int[C*W*H] interleaved pyramid after colour+forward transform.
  * lin : int[C][W*H] planar, raw two's-complement values (before sign-magnitude). */

@@ -37,6 +37,7 @@ def lib():
         L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_inverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_hilbert.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_decode_stage.argtypes = [C.c_void_p, C.c_size_t, C.c_long, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.orc_reconstruct.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Geom), C.c_int, C.c_int]
         L.orc_linearize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Geom), C.c_int]
         _lib = L
@@ -80,6 +81,19 @@ def decode(data, pixels_max=-1):
     arr = np.frombuffer(C.string_at(out, W.value * H.value * Cn.value), dtype=np.uint8)
     _libc.free(out)
     return arr.reshape(H.value, W.value, Cn.value).copy()
+
+
+def decode_stage(data, W, H, Cn, pixels_max=-1):
+    """-> (lin int32 [C, W*H], level, missing int32[48], planes) or None if the stream is unreadable."""
+    lin = np.empty((Cn, W * H), dtype=np.int32)
+    level = C.c_int()
+    missing = np.zeros(48, dtype=np.int32)
+    planes = (C.c_int * 3)()
+    buf = C.create_string_buffer(data, len(data))
+    rc = lib().orc_decode_stage(buf, len(data), pixels_max, lin.ctypes.data, C.byref(level), missing.ctypes.data, planes)
+    if rc:
+        return None
+    return lin, level.value, missing, list(planes)[:Cn]
 
 
 def stage_dump(pix):

@@ -1,0 +1,78 @@
+"""GPU parity: the decoder's entropy stage (dwtx_decode_planes) vs the oracle."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 8, 1), (8, 9, 3), (15, 15, 3), (16, 16, 1), (53, 37, 3), (77, 131, 3), (300, 17, 1), (17, 300, 3),
+          (255, 257, 1), (64, 64, 3), (240, 320, 3), (512, 512, 1), (360, 640, 3)]
+
+
+def check(ctx, data_list, W, H, Cn, levels_max=-1, pixels_max=-1):
+    lin, infos = ctx.decode_planes(data_list, W, H, Cn, levels_max)
+    got = lin.cpu().numpy().reshape(len(data_list), Cn, W * H)
+    for i, data in enumerate(data_list):
+        ref = orc.decode_stage(data, W, H, Cn, pixels_max)
+        if ref is None:
+            assert infos[i].status == 1
+            continue
+        rlin, level, missing, planes = ref
+        assert infos[i].status == 0
+        assert list(infos[i].planes)[:Cn] == planes
+        assert infos[i].level == level
+        assert list(infos[i].missing) == missing.tolist()
+        assert (got[i] == rlin).all()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_full_stream(ctx, shape, kind):
+    H, W, Cn = shape
+    pix = orc.synth(W, H, Cn, 31, kind)
+    data, _ = orc.encode(pix)
+    check(ctx, [data], W, H, Cn)
+
+
+def test_every_prefix_of_a_small_stream(ctx):
+    """Truncation anywhere (decode.c keeps partial planes): all prefixes in one batch."""
+    W, H, Cn = 37, 53, 3
+    data, _ = orc.encode(orc.synth(W, H, Cn, 5, 0))
+    prefixes = [data[:k] for k in range(1, len(data) + 1)]
+    for i in range(0, len(prefixes), 512):
+        check(ctx, prefixes[i:i + 512], W, H, Cn)
+
+
+def test_prefixes_gray_noise(ctx):
+    W, H, Cn = 64, 40, 1
+    data, _ = orc.encode(orc.synth(W, H, Cn, 6, 1))
+    check(ctx, [data[:k] for k in range(1, len(data) + 1, 3)], W, H, Cn)
+
+
+@pytest.mark.parametrize("px", [0, 1, 16, 100, 1000, 5000, 20000, 100000])
+def test_pixels_cap(ctx, px):
+    W, H, Cn = 131, 77, 3
+    data, _ = orc.encode(orc.synth(W, H, Cn, 5, 0))
+    g = orc.geometry(W, H)
+    lm = g.levels
+    while lm > 0 and g.pixels[lm] > px:
+        lm -= 1
+    check(ctx, [data], W, H, Cn, levels_max=lm, pixels_max=px)
+
+
+def test_flat_and_batch(ctx):
+    W, H, Cn = 100, 16, 3
+    imgs = [np.full((H, W, Cn), 77, dtype=np.uint8), orc.synth(W, H, Cn, 1, 0), orc.synth(W, H, Cn, 2, 1)]
+    check(ctx, [orc.encode(p)[0] for p in imgs], W, H, Cn)
+
+
+def test_smpte_golden_stream(ctx):
+    data = open(orc.GOLDEN + "/smpte.dwt", "rb").read()
+    check(ctx, [data, data[:4096], data[:100]], 320, 240, 3)
+
+
+def test_bad_headers(ctx):
+    data, _ = orc.encode(orc.synth(64, 64, 1, 1, 0))
+    _, infos = ctx.decode_planes([b"X" + data[1:], data[:5], data[:6], data], 64, 64, 1)
+    assert [i.status for i in infos] == [1, 1, 1, 0]
