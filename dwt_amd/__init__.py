@@ -188,3 +188,49 @@ class Context:
                                            C.cast(infos, C.c_void_p)), "dwtx_decode_planes")
         self._keep = (dev, lens)   # kernels after the internal sync still read the streams
         return lin, list(infos)
+
+    # -- whole images (host numpy in/out; what the CLIs do) ---------------------
+
+    def encode(self, pix, capacity=0):
+        """uint8 numpy [n,H,W,C] (or [H,W,C]) -> list of .dwt byte strings, list of Stats."""
+        import numpy as np
+
+        single = pix.ndim == 3
+        pix = np.ascontiguousarray(pix[None] if single else pix, dtype=np.uint8)
+        n, H, W, Cn = pix.shape
+        stride = self.lib.dwtx_encode_bound(W, H, Cn) if capacity <= 0 else (capacity + 15) // 8 * 8
+        out = np.empty((n, stride), dtype=np.uint8)
+        lens = (C.c_size_t * n)()
+        stats = (Stats * n)()
+        _check(self.lib.dwtx_encode_images(self.h, pix.ctypes.data, W, H, Cn, n, capacity, out.ctypes.data, stride,
+                                           C.cast(lens, C.c_void_p), C.cast(stats, C.c_void_p)), "dwtx_encode_images")
+        streams = [out[i, : lens[i]].tobytes() for i in range(n)]
+        return (streams[0], stats[0]) if single else (streams, list(stats))
+
+    def decode(self, streams, pixels_max=-1):
+        """.dwt byte string (or list of same-geometry ones) -> uint8 numpy [h,w,C] (or list); None if unreadable."""
+        import numpy as np
+
+        single = isinstance(streams, (bytes, bytearray))
+        lst = [streams] if single else list(streams)
+        n = len(lst)
+        if len(lst[0]) < 6:
+            raise DwtxError(-3, "dwtx_decode_images (short header)")
+        W = (lst[0][2] | (lst[0][3] << 8)) + 1
+        H = (lst[0][4] | (lst[0][5] << 8)) + 1
+        Cn = 3 if lst[0][1:2] == b"6" else 1
+        stride = (max(len(s) for s in lst) + 64 + 7) // 8 * 8
+        host = np.zeros((n, stride), dtype=np.uint8)
+        for i, s in enumerate(lst):
+            host[i, : len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+        lens = (C.c_size_t * n)(*[len(s) for s in lst])
+        pstride = W * H * Cn
+        pix = np.empty((n, pstride), dtype=np.uint8)
+        ow, oh, oc = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        rc = self.lib.dwtx_decode_images(self.h, host.ctypes.data, stride, C.cast(lens, C.c_void_p), n, pixels_max,
+                                         pix.ctypes.data, pstride, ow, oh, oc)
+        if rc == -1 and single:
+            return None
+        _check(rc, "dwtx_decode_images")
+        outs = [pix[i, : ow[i] * oh[i] * oc[i]].reshape(oh[i], ow[i], oc[i]).copy() if ow[i] else None for i in range(n)]
+        return outs[0] if single else outs

@@ -71,6 +71,11 @@ SYMBOLS = {
     "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_linearization": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_reconstruction": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "dwtx_encode_bound": (_sz, [_i, _i, _i]),
+    "dwtx_encode_device": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp]),
+    "dwtx_decode_device": (_i, [_vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "dwtx_encode_images": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp, _vp]),
+    "dwtx_decode_images": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "dwtx_decode_planes": (_i, [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp]),
     "dwtx_encode_planes": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp]),
 }

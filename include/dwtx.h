@@ -162,6 +162,33 @@ int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *dev_lin, int W, int H, int 
 int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *dev_lin, const uint8_t *dev_streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info);
 
+/* ---- whole-image pipelines (batches of n same-geometry images) -------------- */
+
+/* A safe out_stride for unlimited-capacity encodes of W*H*C images (multiple of 8). */
+size_t dwtx_encode_bound(int W, int H, int C);
+
+/* encode.c:155-221 with everything resident in HBM: 8-bit interleaved pixels
+ * [n][H][W][C] -> n streams at dev_out + i*out_stride.  Asynchronous. */
+int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int C, int n, long capacity,
+	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info);
+
+/* decode.c:174-264 with everything resident in HBM.  Image i is written densely
+ * at dev_pix + i*pix_stride with the size the stream supports
+ * (widths/heights[host_info[i].level + 1], decode.c:251-254).  Synchronises once
+ * (after the token walk) to learn that size. */
+int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, size_t stream_stride,
+	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max,
+	uint8_t *dev_pix, size_t pix_stride, dwtx_decode_info *host_info);
+
+/* Host-buffer wrappers: what encode.c:133-232 / decode.c:136-268 do between
+ * read_pnm/write_pnm and the byte sink.  pixels_max < 0 = no PIXELS argument.
+ * dwtx_decode_images returns DWTX_ERR_ARG for a bad header and DWTX_ERR_IO when
+ * the root image or plane counts cannot be read (both exit code 1 in decode.c). */
+int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *host_pix, int W, int H, int C, int n, long capacity,
+	uint8_t *host_out, size_t out_stride, size_t *out_lens, dwtx_stats *stats);
+int dwtx_decode_images(dwtx_ctx *ctx, const uint8_t *host_streams, size_t stream_stride, const size_t *lens, int n,
+	int pixels_max, uint8_t *host_pix, size_t pix_stride, int *outW, int *outH, int *outC);
+
 #ifdef __cplusplus
 }
 #endif

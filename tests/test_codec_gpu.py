@@ -1,0 +1,100 @@
+"""GPU parity, whole path: pixels -> .dwt -> pixels through the C ABI vs the oracle and the goldens."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(orc.GOLDEN, "golden.json")))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def case_input(rec):
+    if rec["seed"] is None:
+        return orc.read_pnm(os.path.join(orc.GOLDEN, "smpte.pnm"))
+    return orc.synth(rec["W"], rec["H"], rec["C"], rec["seed"], rec["kind"])
+
+
+@pytest.mark.parametrize("name", sorted(G))
+def test_goldens_from_the_real_reference(ctx, name):
+    rec = G[name]
+    pix = case_input(rec)
+    data, st = ctx.encode(pix, rec["capacity"])
+    assert len(data) == rec["dwt_len"] and sha(data) == rec["dwt_sha256"]
+    lines = [f"{st.meta_bits} bits for meta data", f"{st.root_bits} bits for root image",
+             f"{st.total_bits} bits ({st.kib} KiB) encoded"]
+    assert lines == rec["encode_stderr"]
+    px = rec["pixels_arg"]
+    back = ctx.decode(data, -1 if px is None else px)
+    assert back.shape[:2] == (rec["dec_H"], rec["dec_W"])
+    assert sha(back.tobytes()) == rec["dec_sha256"]
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 1), (9, 8, 3), (77, 131, 3), (300, 17, 1), (255, 257, 3), (33, 1000, 1)])
+def test_roundtrip_and_oracle_bytes(ctx, shape):
+    H, W, Cn = shape
+    for kind in (0, 1):
+        pix = orc.synth(W, H, Cn, 77, kind)
+        data, _ = ctx.encode(pix)
+        assert data == orc.encode(pix)[0]
+        assert (ctx.decode(data) == pix).all()
+
+
+def test_truncated_decodes_match_oracle(ctx):
+    pix = orc.synth(131, 77, 3, 5, 0)
+    full, _ = ctx.encode(pix)
+    for cap in (100, 300, 500, 1000, 3000, 8000, len(full) - 1):
+        data, _ = ctx.encode(pix, cap)
+        assert data == full[:cap]
+        want = orc.decode(data)
+        got = ctx.decode(data)
+        if want is None:
+            assert got is None
+        else:
+            assert got.shape == want.shape and (got == want).all()
+
+
+def test_batch_mixed_truncation(ctx):
+    """A batch whose streams stop at different places decodes image by image (different sizes)."""
+    pix = orc.synth(131, 77, 3, 9, 0)
+    full, _ = ctx.encode(pix)
+    streams = [full, full[:2000], full[:400], full[:150]]
+    outs = ctx.decode(streams)
+    for s, o in zip(streams, outs):
+        want = orc.decode(s)
+        assert o.shape == want.shape and (o == want).all()
+
+
+def test_batch_roundtrip(ctx):
+    n, H, W, Cn = 5, 96, 160, 3
+    pix = np.stack([orc.synth(W, H, Cn, 40 + i, i & 1) for i in range(n)])
+    streams, _ = ctx.encode(pix)
+    for i in range(n):
+        assert streams[i] == orc.encode(pix[i])[0]
+    outs = ctx.decode(streams)
+    for i in range(n):
+        assert (outs[i] == pix[i]).all()
+
+
+def test_flat_image_quirk(ctx):
+    pix = np.full((16, 100, 3), 77, dtype=np.uint8)
+    data, st = ctx.encode(pix)
+    assert data == orc.encode(pix)[0]
+    back = ctx.decode(data)
+    assert back.shape == (8, 50, 3) and (back == orc.decode(data)).all()
+
+
+def test_pixels_argument(ctx):
+    pix = orc.synth(320, 240, 3, 2, 0)
+    data, _ = ctx.encode(pix)
+    for px in (0, 50, 400, 5000, 30000, 1 << 30):
+        want = orc.decode(data, px)
+        got = ctx.decode(data, px)
+        assert got.shape == want.shape and (got == want).all()
