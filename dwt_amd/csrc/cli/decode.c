@@ -1,0 +1,68 @@
+/*
+ * decode — drop-in for the reference's ./decode (decode.c:136-268):
+ *   decode input.dwt output.pnm [PIXELS]
+ * Same argv, "-" for stdin/stdout, exit codes and output bytes, including
+ * truncated streams (resolution drop, dequantisation bias) and the PIXELS cap.
+ */
+#include "../../../include/dwtx.h"
+#include "pnm_io.h"
+
+int main(int argc, char **argv)
+{
+	if (argc < 3 || argc > 4) {
+		fprintf(stderr, "usage: %s input.dwt output.pnm [PIXELS]\n", argv[0]);
+		return 1;
+	}
+	const char *fname = std_name(argv[1], "/dev/stdin");
+	FILE *f = fopen(fname, "rb");
+	if (!f) {
+		fprintf(stderr, "could not open \"%s\" file to read\n", fname);   /* bytes.h:31 */
+		return 1;
+	}
+	size_t len;
+	uint8_t *raw = read_all(f, &len);
+	fclose(f);
+	if (!raw)
+		return 1;
+	if (len < 6) {   /* decode.c:145-155: get_byte() hits EOF inside the header */
+		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);       /* bytes.h:101 */
+		return 1;
+	}
+	if (raw[0] != 'W' || (raw[1] != '5' && raw[1] != '6'))
+		return 1;
+	int W = (raw[2] | (raw[3] << 8)) + 1, H = (raw[4] | (raw[5] << 8)) + 1, C = raw[1] == '6' ? 3 : 1;
+	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)                           /* decode.c:158 */
+		return 1;
+	int pixels_max = -1;
+	if (argc >= 4) {                                                    /* decode.c:165-166 */
+		pixels_max = atoi(argv[3]);
+		if (pixels_max < 0)
+			pixels_max = 0;   /* any negative value drops every level, like 0 */
+	}
+	size_t stride = (len + 64 + 7) / 8 * 8;
+	uint8_t *padded = (uint8_t *)calloc(stride, 1);
+	memcpy(padded, raw, len);
+	free(raw);
+	uint8_t *pix = (uint8_t *)malloc((size_t)W * H * C);
+	dwtx_ctx *ctx;
+	if (dwtx_ctx_create(0, &ctx)) {
+		fprintf(stderr, "%s\n", dwtx_last_error());
+		return 1;
+	}
+	int ow, oh, oc;
+	int rc = dwtx_decode_images(ctx, padded, stride, &len, 1, pixels_max, pix, (size_t)W * H * C, &ow, &oh, &oc);
+	if (rc == DWTX_ERR_IO) {   /* decode.c:181,185: root image or plane counts cut off */
+		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);
+		return 1;
+	}
+	if (rc) {
+		fprintf(stderr, "%s\n", dwtx_last_error());
+		return 1;
+	}
+	if (!pnm_write(argv[2], pix, ow, oh, oc))
+		return 1;
+	dwtx_ctx_destroy(ctx);
+	free(padded);
+	free(pix);
+	return 0;
+}

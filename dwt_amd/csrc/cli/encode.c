@@ -1,0 +1,55 @@
+/*
+ * encode — drop-in for the reference's ./encode (encode.c:133-232):
+ *   encode input.pnm output.dwt [CAPACITY]
+ * Same argv, "-" for stdin/stdout, exit codes (0 ok, 1 on bad args / unreadable
+ * input / size out of range / unwritable output), stderr statistics lines and
+ * .dwt bytes.  The transform and the coder run on the GPU through libdwtx.
+ */
+#include "../../../include/dwtx.h"
+#include "pnm_io.h"
+
+int main(int argc, char **argv)
+{
+	if (argc != 3 && argc != 4) {
+		fprintf(stderr, "usage: %s input.pnm output.dwt [CAPACITY]\n", argv[0]);
+		return 1;
+	}
+	int W, H, C;
+	uint8_t *pix = pnm_read(argv[1], &W, &H, &C);
+	if (!pix || W > 65536 || H > 65536)          /* encode.c:140 */
+		return 1;
+	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)    /* encode.c:145 */
+		return 1;
+	long capacity = argc >= 4 ? atoi(argv[3]) : 0;   /* encode.c:150-152 */
+	dwtx_ctx *ctx;
+	if (dwtx_ctx_create(0, &ctx)) {
+		fprintf(stderr, "%s\n", dwtx_last_error());
+		return 1;
+	}
+	size_t stride = capacity > 0 ? ((size_t)capacity + 15) / 8 * 8 : dwtx_encode_bound(W, H, C);
+	uint8_t *out = (uint8_t *)malloc(stride);
+	size_t len = 0;
+	dwtx_stats st;
+	int rc = dwtx_encode_images(ctx, pix, W, H, C, 1, capacity, out, stride, &len, &st);
+	if (rc) {
+		fprintf(stderr, "%s\n", dwtx_last_error());
+		return 1;
+	}
+	/* bytes.h:40-57: the sink is opened after the transform, before the first byte */
+	const char *fname = std_name(argv[2], "/dev/stdout");
+	FILE *f = fopen(fname, "wb");
+	if (!f) {
+		fprintf(stderr, "could not open \"%s\" file to write\n", fname);
+		return 1;
+	}
+	fprintf(stderr, "%d bits for meta data\n", st.meta_bits);     /* encode.c:176 */
+	fprintf(stderr, "%d bits for root image\n", st.root_bits);    /* encode.c:180 */
+	if (fwrite(out, 1, len, f) != len)
+		fprintf(stderr, "could not write to file \"%s\"\n", argv[2]);   /* bytes.h:80 */
+	fclose(f);
+	fprintf(stderr, "%d bits (%d KiB) encoded\n", st.total_bits, st.kib);   /* encode.c:230 */
+	dwtx_ctx_destroy(ctx);
+	free(out);
+	free(pix);
+	return 0;
+}

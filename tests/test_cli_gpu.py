@@ -1,0 +1,86 @@
+"""GPU: the ./encode and ./decode drop-in CLIs (argv, exit codes, stderr lines, bytes)."""
+import os
+import subprocess
+
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+ENC = os.path.join(orc.ROOT, "bin", "encode")
+DEC = os.path.join(orc.ROOT, "bin", "decode")
+SMPTE = os.path.join(orc.GOLDEN, "smpte.pnm")
+
+
+def run(*cmd, stdin=None):
+    return subprocess.run(list(cmd), input=stdin, capture_output=True, timeout=300)
+
+
+def test_smpte_files_and_stderr(tmp_path):
+    dwt, pnm = str(tmp_path / "a.dwt"), str(tmp_path / "a.pnm")
+    r = run(ENC, SMPTE, dwt)
+    assert r.returncode == 0
+    assert r.stderr.decode().splitlines() == ["48 bits for meta data", "559 bits for root image",
+                                              "81174 bits (10 KiB) encoded"]
+    assert open(dwt, "rb").read() == open(os.path.join(orc.GOLDEN, "smpte.dwt"), "rb").read()
+    r = run(DEC, dwt, pnm)
+    assert r.returncode == 0
+    back = orc.read_pnm(pnm)
+    assert (back == orc.read_pnm(SMPTE)).all()
+    assert open(pnm, "rb").read().startswith(b"P6 320 240 255\n")
+
+
+def test_stdin_stdout_pipes():
+    src = open(SMPTE, "rb").read()
+    r = run(ENC, "-", "-", stdin=src)
+    assert r.returncode == 0 and r.stdout == open(os.path.join(orc.GOLDEN, "smpte.dwt"), "rb").read()
+    r2 = run(DEC, "-", "-", stdin=r.stdout)
+    assert r2.returncode == 0 and r2.stdout.startswith(b"P6 320 240 255\n")
+    assert r2.stdout[len(b"P6 320 240 255\n"):] == orc.read_pnm(SMPTE).tobytes()
+
+
+def test_capacity_and_pixels_arguments(tmp_path):
+    dwt, pnm = str(tmp_path / "a.dwt"), str(tmp_path / "a.pnm")
+    for cap in (100, 4096):
+        r = run(ENC, SMPTE, dwt, str(cap))
+        assert r.returncode == 0
+        assert open(dwt, "rb").read() == open(os.path.join(orc.GOLDEN, f"smpte_cap{cap}.dwt"), "rb").read()
+        assert run(DEC, dwt, pnm).returncode == 0
+        want = orc.decode(open(dwt, "rb").read())
+        assert (orc.read_pnm(pnm) == want).all()
+    full = os.path.join(orc.GOLDEN, "smpte.dwt")
+    for px in (0, 300, 5000):
+        assert run(DEC, full, pnm, str(px)).returncode == 0
+        assert (orc.read_pnm(pnm) == orc.decode(open(full, "rb").read(), px)).all()
+
+
+def test_exit_codes(tmp_path):
+    assert run(ENC).returncode == 1
+    assert run(DEC, "a").returncode == 1
+    assert run(ENC, str(tmp_path / "missing.pnm"), str(tmp_path / "o.dwt")).returncode == 1
+    small = str(tmp_path / "small.pnm")
+    orc.write_pnm(small, orc.synth(7, 20, 1, 0, 0))
+    assert run(ENC, small, str(tmp_path / "o.dwt")).returncode == 1          # encode.c:145
+    bad = str(tmp_path / "bad.dwt")
+    open(bad, "wb").write(b"X5" + bytes(20))
+    assert run(DEC, bad, str(tmp_path / "o.pnm")).returncode == 1            # decode.c:146
+    open(bad, "wb").write(open(os.path.join(orc.GOLDEN, "smpte.dwt"), "rb").read()[:12])
+    assert run(DEC, bad, str(tmp_path / "o.pnm")).returncode == 1            # root image cut off
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not shipped")
+def test_against_reference_binaries(tmp_path):
+    src = str(tmp_path / "i.pnm")
+    for (W, H, Cn, cap) in [(131, 77, 3, 0), (255, 257, 1, 0), (640, 360, 3, 20000), (64, 64, 1, 333)]:
+        orc.write_pnm(src, orc.synth(W, H, Cn, 3, 0))
+        a, b = str(tmp_path / "a.dwt"), str(tmp_path / "b.dwt")
+        extra = [str(cap)] if cap else []
+        ra = run(os.path.join(orc.REF_DIR, "encode"), src, a, *extra)
+        rb = run(ENC, src, b, *extra)
+        assert ra.returncode == rb.returncode == 0
+        assert ra.stderr == rb.stderr
+        assert open(a, "rb").read() == open(b, "rb").read()
+        pa, pb = str(tmp_path / "a.pnm"), str(tmp_path / "b.pnm")
+        assert run(os.path.join(orc.REF_DIR, "decode"), a, pa).returncode == 0
+        assert run(DEC, a, pb).returncode == 0
+        assert open(pa, "rb").read() == open(pb, "rb").read()
