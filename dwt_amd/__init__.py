@@ -76,6 +76,12 @@ class Context:
     def sync(self):
         _check(self.lib.dwtx_sync(self.h), "dwtx_sync")
 
+    def synth_pixels(self, n, H, W, C_, seed0=0, kind=0):
+        """Synthetic uint8 frames [n,H,W,C] rendered on the device (SURVEY.md §8d generator)."""
+        out = self.torch.empty((n, H, W, C_), dtype=self.torch.uint8, device=self.device)
+        _check(self.lib.dwtx_synth_pixels(self.h, _ptr(out), W, H, C_, n, seed0, kind), "dwtx_synth_pixels")
+        return out
+
     # -- stage kernels -------------------------------------------------------
 
     def planes_from_pixels(self, pix):
@@ -234,3 +240,37 @@ class Context:
         _check(rc, "dwtx_decode_images")
         outs = [pix[i, : ow[i] * oh[i] * oc[i]].reshape(oh[i], ow[i], oc[i]).copy() if ow[i] else None for i in range(n)]
         return outs[0] if single else outs
+
+    # -- whole images, device resident (what bench.py times) --------------------
+
+    def encode_device(self, pix, capacity=0, out=None, info=None):
+        """uint8 device tensor [n,H,W,C] -> (streams uint8 [n,stride], info uint8 [n,sizeof(StreamInfo)]) on device; async."""
+        torch = self.torch
+        n, H, W, Cn = pix.shape
+        assert pix.dtype == torch.uint8 and pix.is_contiguous()
+        stride = self.lib.dwtx_encode_bound(W, H, Cn) if capacity <= 0 else (capacity + 15) // 8 * 8
+        if out is None:
+            out = torch.empty((n, stride), dtype=torch.uint8, device=self.device)
+        if info is None:
+            info = torch.empty((n, C.sizeof(StreamInfo)), dtype=torch.uint8, device=self.device)
+        _check(self.lib.dwtx_encode_device(self.h, _ptr(pix), W, H, Cn, n, capacity, _ptr(out), out.shape[1], _ptr(info)),
+               "dwtx_encode_device")
+        return out, info
+
+    def stream_lengths(self, info):
+        """int64 device tensor of stream byte lengths from the info records of encode_device."""
+        off = StreamInfo.nbytes.offset
+        return info[:, off:off + 8].contiguous().view(self.torch.int64).view(-1)
+
+    def decode_device(self, streams, lens, W, H, C_, levels_max=-1, out=None):
+        """device streams [n,stride] + int64 lens -> (uint8 [n, W*H*C] pixels, list of DecodeInfo); syncs once."""
+        torch = self.torch
+        n, stride = streams.shape
+        assert streams.dtype == torch.uint8 and streams.is_contiguous() and stride % 8 == 0
+        assert lens.dtype == torch.int64 and lens.numel() == n
+        if out is None:
+            out = torch.empty((n, W * H * C_), dtype=torch.uint8, device=self.device)
+        infos = (DecodeInfo * n)()
+        _check(self.lib.dwtx_decode_device(self.h, _ptr(streams), stride, _ptr(lens), W, H, C_, n, levels_max,
+                                           _ptr(out), W * H * C_, C.cast(infos, C.c_void_p)), "dwtx_decode_device")
+        return out, list(infos)

@@ -65,6 +65,7 @@ SYMBOLS = {
     "dwtx_download": (_i, [_vp, _vp, _vp, _sz]),
     "dwtx_compute_lengths": (_i, [C.POINTER(_i)] * 4 + [_i, _i, _i]),
     "dwtx_geometry": (_i, [C.POINTER(Geom), _i, _i]),
+    "dwtx_synth_pixels": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_uint, _i]),
     "dwtx_planes_from_pixels": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dwtx_pixels_from_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dwtx_transformation_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i]),

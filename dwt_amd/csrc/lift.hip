@@ -286,6 +286,35 @@ __global__ __launch_bounds__(256) void k_pixels_from_planes(uint8_t *__restrict_
 	}
 }
 
+// Integer-only synthetic frames: seed = frame index, so every box
+// renders identical bytes.  kind 0 "smooth+noise", kind 1 uniform noise.
+__global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ pix, int W, int H, int C, long total,
+	unsigned seed0, int kind)
+{
+	const long per = (long)W * H * C;
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+		const long img = i / per;
+		long r = i - img * per;
+		const unsigned k = (unsigned)(r % C);
+		r /= C;
+		const unsigned x = (unsigned)(r % W), y = (unsigned)(r / W);
+		unsigned u = x * 0x9E3779B1u ^ y * 0x85EBCA77u ^ k * 0xC2B2AE3Du ^ (seed0 + (unsigned)img) * 0x27D4EB2Fu;
+		u ^= u >> 15;
+		u *= 0x2C1B3C6Du;
+		u ^= u >> 12;
+		u *= 0x297A2D39u;
+		u ^= u >> 15;
+		int p;
+		if (kind) {
+			p = (int)(u >> 24);
+		} else {
+			int tx = (int)(x % 192u) - 96, ty = (int)(y % 128u) - 64;
+			p = 40 + (tx < 0 ? -tx : tx) + (ty < 0 ? -ty : ty) + 10 * (int)k + (int)(u >> 29);
+		}
+		pix[i] = (uint8_t)p;
+	}
+}
+
 // transform steps of a W*H plane, fine to coarse: sizes[t] -> sizes[t+1]
 // (encode.c:24-29: recurse while both halves are >= N0; the first step always runs)
 int lift_steps(int W, int H, int *ws, int *hs)
@@ -302,6 +331,17 @@ int lift_steps(int W, int H, int *ws, int *hs)
 }
 
 } // namespace
+
+extern "C" int dwtx_synth_pixels(dwtx_ctx *ctx, uint8_t *pix, int W, int H, int C, int n, unsigned seed0, int kind)
+{
+	if (!ctx || !pix || W < 1 || H < 1 || (C != 1 && C != 3) || n < 1)
+		return DWTX_ERR_ARG;
+	const long total = (long)W * H * C * n;
+	const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
+	hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(256), 0, ctx->stream, pix, W, H, C, total, seed0, kind);
+	DWTX_LAUNCH_CHECK();
+	return DWTX_OK;
+}
 
 extern "C" int dwtx_planes_from_pixels(dwtx_ctx *ctx, int32_t *planes, const uint8_t *pix, int W, int H, int C, int n)
 {

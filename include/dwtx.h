@@ -117,6 +117,11 @@ int dwtx_geometry(dwtx_geom *g, int W, int H);
 
 /* ---- stage kernels (device buffers, batches of n images) ------------------ */
 
+/* Benchmark/test utility (no reference counterpart): render n synthetic 8-bit
+ * frames [n][H][W][C] on the device with the integer-only generator of
+ * SURVEY.md §8d; frame i uses seed seed0+i.  kind 0 = smooth+noise, 1 = noise. */
+int dwtx_synth_pixels(dwtx_ctx *ctx, uint8_t *dev_pix, int W, int H, int C, int n, unsigned seed0, int kind);
+
 /* pnm.h:69-74 widening + image.h:67-72 ycocg_from_rgb (C==3): interleaved
  * 8-bit pixels [n][H][W][C] -> planar int32 [n*C][H][W]. */
 int dwtx_planes_from_pixels(dwtx_ctx *ctx, int32_t *dev_planes, const uint8_t *dev_pix, int W, int H, int C, int n);

@@ -98,3 +98,26 @@ def test_pixels_argument(ctx):
         want = orc.decode(data, px)
         got = ctx.decode(data, px)
         assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 77, 131, 3), (2, 64, 64, 1), (1, 1080, 1920, 3)])
+def test_device_generator_matches_oracle(ctx, shape):
+    n, H, W, Cn = shape
+    for kind in (0, 1):
+        got = ctx.synth_pixels(n, H, W, Cn, seed0=5, kind=kind).cpu().numpy()
+        for i in range(n):
+            assert (got[i] == orc.synth(W, H, Cn, 5 + i, kind)).all()
+
+
+def test_device_resident_roundtrip(ctx):
+    import torch
+
+    n, H, W, Cn = 3, 240, 320, 3
+    pix = ctx.synth_pixels(n, H, W, Cn, seed0=0, kind=0)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    out, infos = ctx.decode_device(streams, lens, W, H, Cn)
+    assert torch.equal(out.view(n, H, W, Cn), pix)
+    host = pix.cpu().numpy()
+    for i in range(n):
+        assert streams[i, : int(lens[i])].cpu().numpy().tobytes() == orc.encode(host[i])[0]
