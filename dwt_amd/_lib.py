@@ -36,6 +36,7 @@ class DecodeInfo(C.Structure):
         ("status", C.c_int), ("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("levels", C.c_int),
         ("planes", C.c_int * 3), ("pmax", C.c_int), ("level", C.c_int), ("nsegs", C.c_int),
         ("truncated", C.c_int), ("missing", C.c_int * 48), ("bits_used", C.c_ulonglong),
+        ("hops", C.c_uint), ("hopped_chunks", C.c_uint), ("walked_tokens", C.c_uint), ("pad", C.c_uint),
     ]
 
 

@@ -33,6 +33,11 @@ constexpr int TILE = 1024;
 constexpr int ROWS = TILE / 64;
 constexpr int MAX_PLANES = 16;
 constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
+constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
+constexpr int CH_BITS = 1 << CH_LOG2;
+constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
+constexpr int LINK_ROUNDS = 8;          // chunks of look-back behind every stitched entry state
+constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
 
 struct UnpackGeom {
 	int levels, C, W, H;
@@ -54,6 +59,8 @@ struct DecInfo {
 	int truncated;         // a segment ended early (EOF) or the PIXELS cap stopped the walk
 	int missing[48];       // decode.c:193-196: planes not fully decoded, [c*16 + l]
 	unsigned long long bits_used;
+	unsigned hops, hopped_chunks;      // walker statistics: jumps over stitched chunks
+	unsigned walked_tokens, pad;       // tokens the walker had to parse itself
 };
 
 struct DWork {
@@ -69,6 +76,22 @@ struct DWork {
 	unsigned *tile_rank;            // [nplanes][NT]
 	long BW;                        // bitmap words per image
 	int NT;
+	// speculative chunk parse (see k_spec): per 128-bit chunk of every stream
+	unsigned short *exitP;          // [n][NCH]   rel | order<<8 where the path from (chunk start, order 0) leaves; 0xffff dead
+	unsigned short *exitQ;          // [n][NCH]   same for the path that arrives from exitP[chunk-1]
+	unsigned long long *cs;         // [n][NCH+1] exclusive prefix of symbols (run+1) along the arriving paths
+	unsigned *ct;                   // [n][NCH+1] exclusive prefix of tokens
+	unsigned *cg;                   // [n][NCH+1] exclusive prefix of "arriving path does not rejoin" flags
+	unsigned long long *part_s;     // [n][NB]
+	unsigned *part_t, *part_g;      // [n][NB]
+	int *hop_seg;                   // [n][w.MAX_HOPS]
+	unsigned *hop_first, *hop_last, *hop_q0;   // [n][w.MAX_HOPS]
+	unsigned *hop_entry;            // [n][MAX_HOPS] 0xffffffff = stitched run (enter at exitP[first-1]); else off | order<<8
+	unsigned *hop_ntok;             // [n][MAX_HOPS] tokens to apply (walker-parsed chunk pieces)
+	unsigned *breaks;               // [n*FAM][NCH] chunk indices whose arriving path does not rejoin, ascending
+	int *nhops;                     // [n]
+	long NCH, NB;
+	long MAX_HOPS;
 };
 
 __device__ __forceinline__ int popc_below(unsigned long long m)
@@ -158,10 +181,10 @@ struct BitmapWriter {
 	unsigned aone, asign;
 	__device__ __forceinline__ void flush()
 	{
-		if (cur >= 0 && aone) {
-			one[cur] = aone;
+		if (cur >= 0 && aone) {   // hop chunks add their bits to the same words later (k_hopbits)
+			atomicOr(one + cur, aone);
 			if (asign)
-				sign[cur] = asign;
+				atomicOr(sign + cur, asign);
 		}
 		aone = asign = 0;
 	}
@@ -177,13 +200,337 @@ struct BitmapWriter {
 	__device__ __forceinline__ void set_sign(unsigned long long pos) { asign |= 1u << (pos & 31); }
 };
 
+
+// ------------------------------------------------- speculative chunk parse ---
+// Under the pass-1 grammar (VLI token + sign bit, rle.h:56-64 / vli.h:67-84) the
+// parser state at a token start is (bit position b, order o) and the next state
+// is a pure function of it: f(b,o) = (b + 2z + o + 2, max(o+z-2, 0)), z = zeros
+// before the next one bit.  Paths that ever share a state coincide from there
+// on, and in practice they do merge within a few tokens.  So every 128-bit chunk
+// is parsed from (chunk start, order 0) [path P, k_spec] and again from the
+// state in which P of the previous chunk arrives [path Q, k_link].  Where Q
+// leaves the chunk in the same state as P, the stream is "stitched": a walker
+// that enters a chunk in the state P of the previous chunk left it in follows Q
+// chunk after chunk, and prefix sums of Q's token and symbol counts let it jump
+// over any number of stitched chunks with a binary search instead of parsing.
+
+struct ChunkWin {
+	unsigned long long w0, w1, w2;
+};
+
+__device__ __forceinline__ ChunkWin chunk_load(const unsigned long long *w64, long n64, long chunk)
+{
+	ChunkWin c;
+	const long i = chunk * (CH_BITS / 64);
+	c.w0 = i < n64 ? w64[i] : 0ull;
+	c.w1 = i + 1 < n64 ? w64[i + 1] : 0ull;
+	c.w2 = i + 2 < n64 ? w64[i + 2] : 0ull;
+	return c;
+}
+
+__device__ __forceinline__ unsigned long long chunk_win(const ChunkWin &c, int off)   // off in [0, 128)
+{
+	const int r = off & 63;
+	const unsigned long long lo = off >> 6 ? c.w1 : c.w0, hi = off >> 6 ? c.w2 : c.w1;
+	return r ? (lo >> r) | (hi << (64 - r)) : lo;
+}
+
+// one token of the pass-1 grammar at order o; false if it cannot be a token this codec wrote
+__device__ __forceinline__ bool token_at(unsigned long long win, int o, int &len, unsigned &run, unsigned &neg, int &next)
+{
+	if (!win)
+		return false;
+	const int z = __builtin_ctzll(win);
+	const int top = o + z;
+	if (top > 31)
+		return false;
+	len = z + top + 2;
+	run = (top ? (unsigned)(win >> (z + 1)) & (unsigned)((1ull << top) - 1ull) : 0u) + (1u << top) - (1u << o);
+	neg = (unsigned)(win >> (z + 1 + top)) & 1u;
+	next = top >= 2 ? top - 2 : 0;
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride, unsigned short *out_exit)
+{
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int vs = blockIdx.y, img = vs / FAM;   // virtual stream = (image, family)
+	if (chunk >= w.NCH)
+		return;
+	const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+	// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
+	// number of bits apart cannot meet while the order stays 0: seed both parities.
+	int off = vs % FAM, o = 0;
+	unsigned short out = 0xffff;
+	for (;;) {
+		int len, next;
+		unsigned run, neg;
+		if (!token_at(chunk_win(c, off), o, len, run, neg, next))
+			break;
+		off += len;
+		o = next;
+		if (off >= CH_BITS) {
+			out = (unsigned short)((off - CH_BITS) | (o << 8));
+			break;
+		}
+	}
+	out_exit[vs * w.NCH + chunk] = out;
+}
+
+// One refinement round: parse chunk i from the state in which the previous
+// round's path left chunk i-1.  After r rounds the entry state of a chunk is what
+// a parse started r chunks earlier (at order 0) arrives with, so it agrees with
+// any other path that has been running for a while.  The last round records the
+// token/symbol counts and whether the exit still moved ("unjoined").
+__global__ __launch_bounds__(256) void k_link(DWork w, const unsigned char *streams, long stream_stride,
+	const unsigned short *in_exit, unsigned short *out_exit, int record)
+{
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int vs = blockIdx.y, img = vs / FAM;
+	if (chunk > w.NCH)
+		return;
+	unsigned long long sym = 0;
+	unsigned tok = 0, unjoined = 1;
+	unsigned short out = 0xffff;
+	if (chunk >= 1 && chunk < w.NCH) {
+		const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
+		if (in != 0xffff) {
+			const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+			int off = in & 0xff, o = in >> 8;
+			bool dead = false;
+			while (off < CH_BITS) {
+				int len, next;
+				unsigned run, neg;
+				if (!token_at(chunk_win(c, off), o, len, run, neg, next)) {
+					dead = true;
+					break;
+				}
+				off += len;
+				o = next;
+				++tok;
+				sym += (unsigned long long)run + 1ull;
+			}
+			if (!dead) {
+				out = (unsigned short)((off - CH_BITS) | (o << 8));
+				unjoined = out == in_exit[vs * w.NCH + chunk] ? 0u : 1u;
+			}
+		}
+	}
+	if (out == 0xffff)
+		sym = 1ull << 62;   // never hopped over
+	if (chunk < w.NCH)
+		out_exit[vs * w.NCH + chunk] = out;
+	else
+		sym = 0, tok = 0, unjoined = 0;   // sentinel element: its exclusive prefix is the grand total
+	if (!record)
+		return;
+	w.cs[vs * (w.NCH + 1) + chunk] = sym;
+	w.ct[vs * (w.NCH + 1) + chunk] = tok;
+	w.cg[vs * (w.NCH + 1) + chunk] = unjoined;
+}
+
+// three-kernel exclusive scan of (cs, ct, cg) over the NCH+1 elements of every image
+struct Tri {
+	unsigned long long s;
+	unsigned t, g;
+};
+
+__device__ __forceinline__ Tri tri_add(Tri a, Tri b)
+{
+	Tri r = { a.s + b.s, a.t + b.t, a.g + b.g };
+	return r;
+}
+
+__device__ __forceinline__ Tri tri_shfl_up(Tri v, int o)
+{
+	Tri r;
+	r.s = __shfl_up(v.s, o);
+	r.t = __shfl_up(v.t, o);
+	r.g = __shfl_up(v.g, o);
+	return r;
+}
+
+// block-wide (256 threads) exclusive scan; returns this thread's prefix and the block total
+__device__ __forceinline__ Tri block_scan_tri(Tri v, Tri *wsum, Tri &total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	Tri inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const Tri t = tri_shfl_up(inc, o);
+		if (lane >= o)
+			inc = tri_add(inc, t);
+	}
+	if (lane == 63)
+		wsum[wv] = inc;
+	__syncthreads();
+	Tri off = { 0, 0, 0 }, all = { 0, 0, 0 };
+	for (int k = 0; k < 4; ++k) {
+		if (k < wv)
+			off = tri_add(off, wsum[k]);
+		all = tri_add(all, wsum[k]);
+	}
+	__syncthreads();
+	total = all;
+	Tri ex = { off.s + inc.s - v.s, off.t + inc.t - v.t, off.g + inc.g - v.g };
+	return ex;
+}
+
+__global__ __launch_bounds__(256) void k_scan_local(DWork w)
+{
+	__shared__ Tri wsum[4];
+	const int img = blockIdx.y;
+	const long base = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+	const long n = w.NCH + 1;
+	unsigned long long *cs = w.cs + img * n;
+	unsigned *ct = w.ct + img * n, *cg = w.cg + img * n;
+	Tri e[4], run = { 0, 0, 0 };
+	for (int q = 0; q < 4; ++q) {
+		const long i = base + q;
+		Tri v = { 0, 0, 0 };
+		if (i < n) {
+			v.s = cs[i];
+			v.t = ct[i];
+			v.g = cg[i];
+		}
+		e[q] = run;
+		run = tri_add(run, v);
+	}
+	Tri total;
+	const Tri pre = block_scan_tri(run, wsum, total);
+	for (int q = 0; q < 4; ++q) {
+		const long i = base + q;
+		if (i < n) {
+			cs[i] = pre.s + e[q].s;
+			ct[i] = pre.t + e[q].t;
+			cg[i] = pre.g + e[q].g;
+		}
+	}
+	if (threadIdx.x == 0) {
+		w.part_s[img * w.NB + blockIdx.x] = total.s;
+		w.part_t[img * w.NB + blockIdx.x] = total.t;
+		w.part_g[img * w.NB + blockIdx.x] = total.g;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_scan_parts(DWork w)
+{
+	__shared__ Tri wsum[4];
+	const int img = blockIdx.x;
+	Tri carry = { 0, 0, 0 };
+	for (long b0 = 0; b0 < w.NB; b0 += 256) {
+		const long i = b0 + threadIdx.x;
+		Tri v = { 0, 0, 0 };
+		if (i < w.NB) {
+			v.s = w.part_s[img * w.NB + i];
+			v.t = w.part_t[img * w.NB + i];
+			v.g = w.part_g[img * w.NB + i];
+		}
+		Tri total;
+		const Tri pre = block_scan_tri(v, wsum, total);
+		if (i < w.NB) {
+			w.part_s[img * w.NB + i] = carry.s + pre.s;
+			w.part_t[img * w.NB + i] = carry.t + pre.t;
+			w.part_g[img * w.NB + i] = carry.g + pre.g;
+		}
+		carry = tri_add(carry, total);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(DWork w)
+{
+	const int img = blockIdx.y;
+	const long n = w.NCH + 1;
+	const unsigned long long ps = w.part_s[img * w.NB + blockIdx.x];
+	const unsigned pt = w.part_t[img * w.NB + blockIdx.x], pg = w.part_g[img * w.NB + blockIdx.x];
+	for (int q = 0; q < 4; ++q) {
+		const long i = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + q;
+		if (i < n) {
+			w.cs[img * n + i] += ps;
+			w.ct[img * n + i] += pt;
+			w.cg[img * n + i] += pg;
+		}
+	}
+}
+
+// compact list of the unjoined chunks: the one with rank r (= cg[i], exclusive prefix) goes to slot r
+__global__ __launch_bounds__(256) void k_breaks(DWork w)
+{
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int vs = blockIdx.y;
+	if (chunk >= w.NCH)
+		return;
+	const unsigned *cg = w.cg + (long)vs * (w.NCH + 1);
+	if (cg[chunk + 1] != cg[chunk])
+		w.breaks[(long)vs * w.NCH + cg[chunk]] = (unsigned)chunk;
+}
+
+// the tokens of every chunk (piece) the walker did not set itself -> onebits / signbits
+__global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
+{
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int img = blockIdx.y;
+	if (chunk >= w.NCH || chunk < 1)
+		return;
+	const int nh = w.nhops[img];
+	const unsigned *hf = w.hop_first + (long)img * w.MAX_HOPS, *hl = w.hop_last + (long)img * w.MAX_HOPS;
+	int lo = 0, hi = nh;   // records are in stream order: first h with hl[h] >= chunk
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (hl[mid] < (unsigned)chunk)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	unsigned *one = w.onebits + img * w.BW, *sgn = w.signbits + img * w.BW;
+	const long n = w.NCH + 1;
+	ChunkWin c;
+	bool loaded = false;
+	for (int h = lo; h < nh && hf[h] <= (unsigned)chunk; ++h) {
+		const int hs = w.hop_seg[(long)img * w.MAX_HOPS + h];
+		const int k = hs & 0xffff, vs = img * FAM + (hs >> 16);
+		if ((w.seg_desc[(long)img * MAX_SEGS + k] >> 8) == 0)
+			continue;   // plane -1 (flat image): symbols carry no bits
+		if (!loaded) {
+			c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+			loaded = true;
+		}
+		unsigned long long pos = w.seg_symbase[(long)img * MAX_SEGS + k] + w.hop_q0[(long)img * w.MAX_HOPS + h];
+		const unsigned entry = w.hop_entry[(long)img * w.MAX_HOPS + h];
+		unsigned left = w.hop_ntok[(long)img * w.MAX_HOPS + h];
+		int off, o;
+		if (entry == 0xffffffffu) {
+			pos += w.cs[vs * n + chunk] - w.cs[vs * n + hf[h]];
+			const unsigned short in = w.exitP[vs * w.NCH + chunk - 1];
+			off = in & 0xff;
+			o = in >> 8;
+		} else {
+			off = (int)(entry & 0xff);
+			o = (int)(entry >> 8);
+		}
+		while (off < CH_BITS && left) {
+			int len, next;
+			unsigned run, neg;
+			if (!token_at(chunk_win(c, off), o, len, run, neg, next))
+				break;
+			off += len;
+			o = next;
+			pos += run;
+			atomicOr(one + (pos >> 5), 1u << (pos & 31));
+			if (neg)
+				atomicOr(sgn + (pos >> 5), 1u << (pos & 31));
+			++pos;
+			--left;
+		}
+	}
+}
+
 // --------------------------------------------------------------- k_tokenize ---
 
 __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
 	const unsigned long long *lens, int *lin, int n)
 {
-	const int img = blockIdx.x * blockDim.x + threadIdx.x;
-	if (img >= n)
+	const int img = blockIdx.x;
+	if (img >= n || threadIdx.x)
 		return;
 	DecInfo &I = w.info[img];
 	I.status = 1;
@@ -261,6 +608,23 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	unsigned long long symtotal = 0;
 	int nsegs = 0, level = -1;
 
+	// stitched-chunk tables of this stream (k_spec / k_link / k_scan_* / k_breaks)
+	const unsigned short *exitP0 = w.exitP + (long)img * FAM * w.NCH, *exitQ0 = w.exitQ + (long)img * FAM * w.NCH;
+	const unsigned long long *CS0 = w.cs + (long)img * FAM * (w.NCH + 1);
+	const unsigned *CT0 = w.ct + (long)img * FAM * (w.NCH + 1), *CG0 = w.cg + (long)img * FAM * (w.NCH + 1);
+	const unsigned *BR0 = w.breaks + (long)img * FAM * w.NCH;
+	const unsigned long long *s64 = (const unsigned long long *)s8;
+	// chunk i is safe to parse blindly if every token starting in it ends inside the data
+	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
+	long checked = -1;
+	int nhops = 0;
+	unsigned hopped = 0, walked = 0;
+	bool br_synced = true;   // br's look-ahead registers match br.b
+	int *hop_seg = w.hop_seg + (long)img * w.MAX_HOPS;
+	unsigned *hop_first = w.hop_first + (long)img * w.MAX_HOPS, *hop_last = w.hop_last + (long)img * w.MAX_HOPS,
+		*hop_q0 = w.hop_q0 + (long)img * w.MAX_HOPS, *hop_entry = w.hop_entry + (long)img * w.MAX_HOPS,
+		*hop_ntok = w.hop_ntok + (long)img * w.MAX_HOPS;
+
 	// decode.c:67-100 without touching coefficients; false = stop decoding (decode.c:204,221,238)
 	auto segment = [&](int c, int l, int p) -> bool {
 		const int num = g.pixels[l + 1] - g.pixels[l];
@@ -279,12 +643,108 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		bool ok = true;
 		while (q < n1) {
 			unsigned zr;
-			if (cnt == 0) {   // rle.h:70-75
+			if (cnt == 0) {   // rle.h:70-75: a token starts here
+				const long ci = (long)(br.b >> CH_LOG2);
+				if (ci >= 1 && ci <= lastsafe && nhops < w.MAX_HOPS) {
+					const unsigned need = (unsigned)(n1 - q);
+					const int rel = (int)(br.b - ((unsigned long long)ci << CH_LOG2));
+					bool moved = false;
+					if (ci != checked) {
+						checked = ci;
+						for (int fam = 0; fam < FAM && !moved; ++fam) {
+							const unsigned ep = exitP0[fam * w.NCH + ci - 1];
+							if (ep == 0xffffu || (int)(ep & 0xffu) != rel || (int)(ep >> 8) != order)
+								continue;
+							// We stand exactly where this family's path arrives from chunk ci-1, so from here on
+							// the stream IS that stitched path.  It runs unbroken up to the next unjoined chunk
+							// `re`; take all of it if the segment needs that many symbols, else binary-search
+							// the prefix sums for the last chunk that still fits.
+							const unsigned long long *CS = CS0 + fam * (w.NCH + 1);
+							const unsigned *CT = CT0 + fam * (w.NCH + 1), *CG = CG0 + fam * (w.NCH + 1);
+							const unsigned g0 = CG[ci], gtot = CG[w.NCH];
+							const unsigned long long s0 = CS[ci];
+							long hi = g0 < gtot ? (long)BR0[fam * w.NCH + g0] : lastsafe;
+							hi = hi < lastsafe ? hi : lastsafe;
+							long lo = ci - 1;
+							if (hi >= ci && CS[hi + 1] - s0 <= (unsigned long long)need) {
+								lo = hi;
+							} else {
+								hi = hi - 1;
+								while (lo < hi) {
+									const long mid = (lo + hi + 1) >> 1;
+									if (CS[mid + 1] - s0 <= (unsigned long long)need)
+										lo = mid;
+									else
+										hi = mid - 1;
+								}
+							}
+							if (lo >= ci) {
+								hop_seg[nhops] = k | (fam << 16);
+								hop_first[nhops] = (unsigned)ci;
+								hop_last[nhops] = (unsigned)lo;
+								hop_q0[nhops] = (unsigned)q;
+								hop_entry[nhops] = 0xffffffffu;
+								hop_ntok[nhops] = 0xffffffffu;
+								++nhops;
+								hopped += (unsigned)(lo - ci + 1);
+								q += (int)(CS[lo + 1] - s0);
+								ones += (int)(CT[lo + 1] - CT[ci]);
+								const unsigned eq = exitQ0[fam * w.NCH + lo];
+								order = (int)(eq >> 8);
+								br.b = ((unsigned long long)(lo + 1) << CH_LOG2) + (eq & 0xffu);
+								br_synced = false;
+								moved = true;
+							}
+						}
+					}
+					if (!moved) {
+						// parse the rest of this chunk ourselves, counting only; k_hopbits sets the bits later
+						const ChunkWin cw = chunk_load(s64, br.n64, ci);
+						int off = rel, o = order;
+						unsigned tok = 0;
+						unsigned long long sym = 0;
+						while (off < CH_BITS) {
+							int len, next;
+							unsigned run, neg;
+							if (!token_at(chunk_win(cw, off), o, len, run, neg, next))
+								break;
+							if (sym + run + 1 > (unsigned long long)need)
+								break;   // this token's run reaches past the segment: the careful path below takes it
+							sym += (unsigned long long)run + 1;
+							++tok;
+							off += len;
+							o = next;
+						}
+						if (tok) {
+							hop_seg[nhops] = k;
+							hop_first[nhops] = (unsigned)ci;
+							hop_last[nhops] = (unsigned)ci;
+							hop_q0[nhops] = (unsigned)q;
+							hop_entry[nhops] = (unsigned)rel | ((unsigned)order << 8);
+							hop_ntok[nhops] = tok;
+							++nhops;
+							walked += tok;
+							q += (int)sym;
+							ones += (int)tok;
+							order = o;
+							br.b = ((unsigned long long)ci << CH_LOG2) + (unsigned)off;
+							br_synced = false;
+							moved = true;
+						}
+					}
+					if (moved)
+						continue;
+				}
+				if (!br_synced) {
+					br.seek(br.b);
+					br_synced = true;
+				}
 				unsigned v;
 				if (!br.vli(order, v)) {
 					ok = false;
 					break;
 				}
+				++walked;
 				zr = v;
 			} else {
 				zr = cnt - 1;
@@ -300,6 +760,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			if (p >= 0)
 				bm.set_one(sym0 + (unsigned)q);
 			++ones;
+			if (!br_synced) {
+				br.seek(br.b);
+				br_synced = true;
+			}
 			unsigned neg;
 			if (!br.read(1, neg)) {     // magnitude bit stays, sign unknown (decode.c:80-85)
 				++q;
@@ -328,7 +792,8 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 				return false;
 			}
 			sn2[k] = (unsigned)n2;
-			br.seek(br.b + (unsigned)n2);
+			br.b += (unsigned)n2;
+			br_synced = false;
 		}
 		return true;
 	};
@@ -375,6 +840,11 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		}
 	}
 	bm.flush();
+	w.nhops[img] = nhops;
+	I.hops = (unsigned)nhops;
+	I.hopped_chunks = hopped;
+	I.walked_tokens = walked;
+	I.pad = 0;
 	I.level = level;
 	I.nsegs = nsegs;
 	I.truncated = stop ? 1 : 0;
@@ -514,7 +984,7 @@ __global__ __launch_bounds__(256) void k_finish(UnpackGeom g, int *lin, int npla
 
 } // namespace
 
-enum { SLOT_UP_SMALL = 12, SLOT_UP_BITS, SLOT_UP_TILES };
+enum { SLOT_UP_SMALL = 12, SLOT_UP_BITS, SLOT_UP_TILES, SLOT_UP_CHUNKS };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -546,6 +1016,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	const int nplanes = n * C;
 
 	DWork w;
+	unsigned short *spare_exit = nullptr;
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
@@ -580,14 +1051,78 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.signbits = bits + (size_t)n * w.BW;
 		w.tile_sig = (unsigned short *)(tiles + o_ts);
 		w.tile_rank = (unsigned *)(tiles + o_tr);
+		// speculative chunk tables
+		w.NCH = (long)((stream_stride * 8 + CH_BITS - 1) / CH_BITS);
+		w.NB = (w.NCH + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+		off = 0;
+		w.MAX_HOPS = 8 * MAX_SEGS + w.NCH / 8;
+		const size_t o_ep = take(sizeof(short) * (size_t)n * FAM * w.NCH);
+		const size_t o_eq = take(sizeof(short) * (size_t)n * FAM * w.NCH);
+		const size_t o_e2 = take(sizeof(short) * (size_t)n * FAM * w.NCH);
+		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * FAM * (w.NCH + 1));
+		const size_t o_ct = take(sizeof(unsigned) * (size_t)n * FAM * (w.NCH + 1));
+		const size_t o_cg = take(sizeof(unsigned) * (size_t)n * FAM * (w.NCH + 1));
+		const size_t o_ps = take(sizeof(unsigned long long) * (size_t)n * FAM * w.NB);
+		const size_t o_pt = take(sizeof(unsigned) * (size_t)n * FAM * w.NB);
+		const size_t o_pg = take(sizeof(unsigned) * (size_t)n * FAM * w.NB);
+		const size_t o_hs = take(sizeof(int) * (size_t)n * w.MAX_HOPS);
+		const size_t o_hf = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
+		const size_t o_hl = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
+		const size_t o_hq = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
+		const size_t o_he = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
+		const size_t o_hn = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
+		const size_t o_br = take(sizeof(unsigned) * (size_t)n * FAM * w.NCH);
+		const size_t o_nh = take(sizeof(int) * (size_t)n);
+		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
+		if (!chunks)
+			return DWTX_ERR_NOMEM;
+		w.exitP = (unsigned short *)(chunks + o_ep);
+		w.exitQ = (unsigned short *)(chunks + o_eq);
+		spare_exit = (unsigned short *)(chunks + o_e2);
+		w.cs = (unsigned long long *)(chunks + o_cs);
+		w.ct = (unsigned *)(chunks + o_ct);
+		w.cg = (unsigned *)(chunks + o_cg);
+		w.part_s = (unsigned long long *)(chunks + o_ps);
+		w.part_t = (unsigned *)(chunks + o_pt);
+		w.part_g = (unsigned *)(chunks + o_pg);
+		w.hop_seg = (int *)(chunks + o_hs);
+		w.hop_first = (unsigned *)(chunks + o_hf);
+		w.hop_last = (unsigned *)(chunks + o_hl);
+		w.hop_q0 = (unsigned *)(chunks + o_hq);
+		w.hop_entry = (unsigned *)(chunks + o_he);
+		w.hop_ntok = (unsigned *)(chunks + o_hn);
+		w.breaks = (unsigned *)(chunks + o_br);
+		w.nhops = (int *)(chunks + o_nh);
+		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * 2 * (size_t)n * w.BW, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(tiles + o_ts, 0, sizeof(short) * (size_t)nplanes * NT, ctx->stream));
 	}
 	hipStream_t s = ctx->stream;
 	DWTX_HIP(hipMemsetAsync(lin, 0, sizeof(int) * (size_t)nplanes * g.lin_stride, s));   // decode.c:177-179
-	hipLaunchKernelGGL(k_tokenize, dim3(dwtx_cdiv(n, 64)), dim3(64), 0, s, g, w, streams, (long)stream_stride,
-		dev_lens, lin, n);
+	{
+		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), n * FAM);
+		unsigned short *e0 = w.exitP, *e1 = w.exitQ, *e2 = spare_exit;
+		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, s, w, streams, (long)stream_stride, e0);
+		// LINK_ROUNDS-1 refinement rounds rotate through three exit buffers, the last one records.
+		// Walkers enter a chunk in state exitP[chunk-1] and leave it in state exitQ[chunk].
+		unsigned short *bufs[3] = { e0, e1, e2 };
+		int cur = 0;
+		for (int r = 1; r < LINK_ROUNDS; ++r) {
+			const int nxt = (cur + 1) % 3;
+			hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt], 0);
+			cur = nxt;
+		}
+		w.exitP = bufs[cur];
+		w.exitQ = bufs[(cur + 1) % 3];
+		hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, w.exitP, w.exitQ, 1);
+		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
+		hipLaunchKernelGGL(k_scan_parts, dim3(n * FAM), dim3(256), 0, s, w);
+		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
+		hipLaunchKernelGGL(k_breaks, dim3((unsigned)((w.NCH + 255) / 256), n * FAM), dim3(256), 0, s, w);
+	}
+	hipLaunchKernelGGL(k_tokenize, dim3(n), dim3(64), 0, s, g, w, streams, (long)stream_stride, dev_lens, lin, n);
+	hipLaunchKernelGGL(k_hopbits, dim3((unsigned)((w.NCH + 255) / 256), n), dim3(256), 0, s, w, streams, (long)stream_stride);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_decode_info) == sizeof(DecInfo), "DecInfo is the device image of dwtx_decode_info");
 	DWTX_HIP(hipMemcpyAsync(host_info, w.info, sizeof(DecInfo) * (size_t)n, hipMemcpyDeviceToHost, s));

@@ -90,6 +90,8 @@ typedef struct dwtx_decode_info {
 	int truncated;                 /* the walk stopped early (end of data or PIXELS cap) */
 	int missing[48];               /* decode.c:193-196: planes not fully decoded, [channel*16 + level] */
 	unsigned long long bits_used;
+	unsigned hops, hopped_chunks;  /* token walker statistics: jumps over stitched 128-bit chunks */
+	unsigned walked_tokens, pad;   /* tokens the walker parsed itself */
 } dwtx_decode_info;
 
 /* ---- context / memory ---------------------------------------------------- */

@@ -621,10 +621,15 @@ static int src_bits(source *s, int n, int *out)
 	return 0;
 }
 
+/* optional diagnostics hook (tools/merge_sim.c): bit position and order at every VLI token start */
+void (*orc_trace_vli)(size_t bitpos, int order) = 0;
+
 /* vli.h:86-101 */
 static int src_vli(source *s)
 {
 	int sum = 0, b, rem = 0;
+	if (orc_trace_vli)
+		orc_trace_vli(s->pos * 8 - (size_t)s->nacc, s->order);
 	while ((b = src_bit(s)) == 0) {
 		sum += 1 << s->order;
 		++s->order;
