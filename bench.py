@@ -91,6 +91,7 @@ def main():
     import torch.distributed as dist
 
     import dwt_amd
+    from dwt_amd.dist import gather_streams
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,13 +120,7 @@ def main():
         lens = ctx.stream_lengths(inf)
         if world > 1:
             # the one exchange step of the path: lengths, then the streams, to rank 0 over RCCL/xGMI
-            all_lens = torch.empty((world * B,), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(all_lens, lens)
-            width = (int(all_lens.max().item()) + 7) // 8 * 8
-            mine = streams[:, :width].contiguous()
-            bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine, bufs, dst=0)
-            gathered["streams"], gathered["lens"] = bufs, all_lens
+            gathered["streams"], gathered["lens"] = gather_streams(streams, lens, dst=0)
         d, dinfos = ctx.decode_device(streams, lens, W, H, C, out=dec)
         return streams, lens, d, dinfos
 
