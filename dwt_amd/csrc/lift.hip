@@ -22,13 +22,14 @@
 namespace {
 
 constexpr int WAVES = 4;          // waves per block, stacked along y
-constexpr int ROWS_PER_WAVE = 32; // output row pairs per wave strip
+constexpr int MAX_ROWS_PER_WAVE = 32; // output row pairs per wave strip (fewer on small levels, to keep the chip full)
 
 struct LevelArgs {
 	const int *src;  long src_ps;  int spitch;  // forward: input w*h      | inverse: LL (w2*h2)
 	int *ll;         long ll_ps;   int llpitch; // forward: LL out (w2*h2) | inverse: output w*h
 	int *det;        long det_ps;  int dpitch;  // Mallat pyramid: HL at (w2+x, y), LH at (x, h2+y), HH at (w2+x, h2+y)
 	int w, h, w2, h2;
+	int rpw;          // output row pairs per wave strip
 };
 
 // ---------------------------------------------------------------- forward ---
@@ -70,10 +71,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level(LevelArgs a)
 	L.lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	L.k = blockIdx.x * 64 + L.lane;
-	const int j0 = (blockIdx.y * WAVES + wv) * ROWS_PER_WAVE;
+	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
-	const int j1 = min(j0 + ROWS_PER_WAVE, a.h2);
+	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	L.valid = 2 * L.k < a.w;
 	L.has_odd = 2 * L.k + 1 < a.w;
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level(LevelArgs a)
 	const int lane = threadIdx.x & 63;
 	const int wv = threadIdx.x >> 6;
 	L.k = blockIdx.x * INV_PAIRS - 1 + lane;
-	const int j0 = (blockIdx.y * WAVES + wv) * ROWS_PER_WAVE;
+	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
-	const int j1 = min(j0 + ROWS_PER_WAVE, a.h2);
+	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	L.valid = L.k >= 0 && 2 * L.k < a.w;
 	L.has_odd = L.k >= 0 && 2 * L.k + 1 < a.w;
@@ -229,6 +230,382 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level(LevelArgs a)
 	}
 }
 
+
+// ------------------------------------------------------ wide (16-byte) path ---
+// Same algorithm with two column pairs per lane: 16-byte loads of the input rows,
+// 8-byte stores of each subband row (forward) / 8-byte subband loads and 16-byte
+// stores (inverse), and the next rows' loads issued one loop iteration ahead of
+// their use.  Needs w % 4 == 0 and 16-byte aligned rows; other shapes take the
+// narrow kernels above.
+
+struct I2 {
+	int a, b;
+};
+
+struct LevelArgsW {
+	LevelArgs a;
+	int nquads;       // w / 4
+};
+
+struct FwdRaw {
+	int4 x;
+	int xr;           // x[4q+4] for lane 63
+	int2 left;        // x[4q-2], x[4q-1] for lane 0
+};
+
+__device__ __forceinline__ FwdRaw fwd_load_w(const int *__restrict__ row, int q, int lane, int nquads, bool valid)
+{
+	FwdRaw r;
+	r.x = valid ? *reinterpret_cast<const int4 *>(row + 4 * q) : make_int4(0, 0, 0, 0);
+	r.xr = 0;
+	r.left = make_int2(0, 0);
+	if (lane == 63 && valid && q + 1 < nquads)
+		r.xr = row[4 * q + 4];
+	if (lane == 0 && valid && q > 0)
+		r.left = *reinterpret_cast<const int2 *>(row + 4 * q - 2);
+	return r;
+}
+
+__device__ __forceinline__ void fwd_lift_w(const FwdRaw &r, int q, int lane, int nquads, I2 &lo, I2 &hi)
+{
+	int xr = __shfl_down(r.x.x, 1);
+	if (lane == 63)
+		xr = r.xr;
+	if (q + 1 >= nquads)
+		xr = r.x.z;                       // x[w] := x[w-2]
+	const int d0 = r.x.y - tdiv2(r.x.x + r.x.z);
+	const int d1 = r.x.w - tdiv2(r.x.z + xr);
+	int dl = __shfl_up(d1, 1);
+	if (lane == 0)
+		dl = r.left.y - tdiv2(r.left.x + r.x.x);
+	if (q == 0)
+		dl = d0;                          // d[-1] := d[0]
+	lo.a = r.x.x + tdiv4(dl + d0);
+	lo.b = r.x.z + tdiv4(d0 + d1);
+	hi.a = d0;
+	hi.b = d1;
+}
+
+__device__ __forceinline__ I2 i2_pred(I2 odd, I2 e0, I2 e2)
+{
+	I2 r = { odd.a - tdiv2(e0.a + e2.a), odd.b - tdiv2(e0.b + e2.b) };
+	return r;
+}
+
+__device__ __forceinline__ I2 i2_upd(I2 even, I2 dprev, I2 d)
+{
+	I2 r = { even.a + tdiv4(dprev.a + d.a), even.b + tdiv4(dprev.b + d.b) };
+	return r;
+}
+
+__device__ __forceinline__ void st2(int *p, I2 v)
+{
+	*reinterpret_cast<int2 *>(p) = make_int2(v.a, v.b);
+}
+
+__global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
+{
+	const LevelArgs &a = A.a;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int q = blockIdx.x * 64 + lane;
+	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	if (j0 >= a.h2)
+		return;
+	const int j1 = min(j0 + a.rpw, a.h2);
+	const int plane = blockIdx.z;
+	const bool valid = q < A.nquads;
+	const int *src = a.src + plane * a.src_ps;
+	int *ll = a.ll + plane * a.ll_ps;
+	int *det = a.det + plane * a.det_ps;
+
+	int jj = j0 > 0 ? j0 - 1 : 0;
+	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
+	{
+		const FwdRaw r0 = fwd_load_w(src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid);
+		fwd_lift_w(r0, q, lane, A.nquads, l0, h0);
+	}
+	// rows 2jj+1 and 2jj+2 of the coming iteration, loaded one iteration ahead
+	FwdRaw n1 = fwd_load_w(src + (long)min(2 * jj + 1, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+	FwdRaw n2 = fwd_load_w(src + (long)min(2 * jj + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+	for (; jj < j1; ++jj) {
+		const int r1 = 2 * jj + 1, r2 = r1 + 1;
+		const bool odd_in = r1 < a.h;
+		const FwdRaw c1 = n1, c2 = n2;
+		if (jj + 1 < j1) {
+			n1 = fwd_load_w(src + (long)min(r1 + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+			n2 = fwd_load_w(src + (long)min(r2 + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+		}
+		I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
+		if (odd_in)
+			fwd_lift_w(c1, q, lane, A.nquads, l1, h1);
+		if (r2 < a.h)
+			fwd_lift_w(c2, q, lane, A.nquads, l2, h2v);
+		const I2 dl = i2_pred(l1, l0, l2);
+		const I2 dh = i2_pred(h1, h0, h2v);
+		if (jj >= j0 && valid) {
+			I2 sl = l0, sh = h0;
+			if (odd_in) {
+				sl = i2_upd(l0, jj ? pl : dl, dl);
+				sh = i2_upd(h0, jj ? ph : dh, dh);
+			}
+			st2(ll + (long)jj * a.llpitch + 2 * q, sl);
+			st2(det + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
+			if (odd_in) {
+				st2(det + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
+				st2(det + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+			}
+		}
+		pl = dl;
+		ph = dh;
+		l0 = l2;
+		h0 = h2v;
+	}
+}
+
+struct InvRaw {
+	int2 sl, sh, dl, dh;   // LL | HL | LH | HH samples of one row pair
+};
+
+__device__ __forceinline__ InvRaw inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, int qd, bool valid)
+{
+	InvRaw r;
+	r.sl = r.sh = r.dl = r.dh = make_int2(0, 0);
+	if (valid && j < a.h2) {
+		r.sl = *reinterpret_cast<const int2 *>(llp + (long)j * a.spitch + 2 * qd);
+		r.sh = *reinterpret_cast<const int2 *>(det + (long)j * a.dpitch + a.w2 + 2 * qd);
+		if (2 * j + 1 < a.h) {
+			r.dl = *reinterpret_cast<const int2 *>(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
+			r.dh = *reinterpret_cast<const int2 *>(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
+		}
+	}
+	return r;
+}
+
+__device__ __forceinline__ I2 to_i2(int2 v)
+{
+	I2 r = { v.x, v.y };
+	return r;
+}
+
+// horizontal inverse of one output row for this lane's two pairs
+__device__ __forceinline__ void inv_row_w(int *__restrict__ row, int qd, int nquads, bool writes, I2 lo, I2 hi)
+{
+	int hl = __shfl_up(hi.b, 1);
+	if (qd <= 0)
+		hl = hi.a;
+	const int e0 = lo.a - tdiv4(hl + hi.a);
+	const int e1 = lo.b - tdiv4(hi.a + hi.b);
+	int er = __shfl_down(e0, 1);
+	if (qd + 1 >= nquads)
+		er = e1;
+	const int o0 = hi.a + tdiv2(e0 + e1);
+	const int o1 = hi.b + tdiv2(e1 + er);
+	if (writes)
+		*reinterpret_cast<int4 *>(row + 4 * qd) = make_int4(e0, o0, e1, o1);
+}
+
+__global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
+{
+	const LevelArgs &a = A.a;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int qd = blockIdx.x * INV_PAIRS - 1 + lane;
+	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	if (j0 >= a.h2)
+		return;
+	const int j1 = min(j0 + a.rpw, a.h2);
+	const int plane = blockIdx.z;
+	const bool valid = qd >= 0 && qd < A.nquads;
+	const bool writes = valid && lane >= 1 && lane <= INV_PAIRS;
+	const int *llp = a.src + plane * a.src_ps;
+	const int *det = a.det + plane * a.det_ps;
+	int *dst = a.ll + plane * a.ll_ps;
+	const bool h_odd = a.h & 1;
+
+	auto even_of = [&](int j, I2 s, I2 dprev, I2 dcur) {
+		if (h_odd && 2 * j == a.h - 1)
+			return s;
+		const I2 dp = j ? dprev : dcur;
+		I2 r = { s.a - tdiv4(dp.a + dcur.a), s.b - tdiv4(dp.b + dcur.b) };
+		return r;
+	};
+
+	I2 pdl = { 0, 0 }, pdh = { 0, 0 };
+	if (j0 > 0) {
+		const InvRaw p = inv_load_w(a, llp, det, j0 - 1, qd, valid);
+		pdl = to_i2(p.dl);
+		pdh = to_i2(p.dh);
+	}
+	InvRaw cur = inv_load_w(a, llp, det, j0, qd, valid);
+	InvRaw nxt = inv_load_w(a, llp, det, j0 + 1, qd, valid);
+	I2 dl = to_i2(cur.dl), dh = to_i2(cur.dh);
+	I2 el = even_of(j0, to_i2(cur.sl), pdl, dl), eh = even_of(j0, to_i2(cur.sh), pdh, dh);
+	for (int jj = j0; jj < j1; ++jj) {
+		const int r0 = 2 * jj, r1 = r0 + 1;
+		const InvRaw n = nxt;
+		if (jj + 1 < j1)
+			nxt = inv_load_w(a, llp, det, jj + 2, qd, valid);
+		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el, neh = eh;   // mirror x[h] := x[h-2]
+		if (r1 + 1 < a.h) {
+			ndl = to_i2(n.dl);
+			ndh = to_i2(n.dh);
+			nel = even_of(jj + 1, to_i2(n.sl), dl, ndl);
+			neh = even_of(jj + 1, to_i2(n.sh), dh, ndh);
+		}
+		inv_row_w(dst + (long)r0 * a.llpitch, qd, A.nquads, writes, el, eh);
+		if (r1 < a.h) {
+			const I2 ol = { dl.a + tdiv2(el.a + nel.a), dl.b + tdiv2(el.b + nel.b) };
+			const I2 oh = { dh.a + tdiv2(eh.a + neh.a), dh.b + tdiv2(eh.b + neh.b) };
+			inv_row_w(dst + (long)r1 * a.llpitch, qd, A.nquads, writes, ol, oh);
+		}
+		dl = ndl;
+		dh = ndh;
+		el = nel;
+		eh = neh;
+	}
+}
+
+// ------------------------------------------------------------ coarse tail ---
+// Once a plane is at most 64x64 all remaining levels run in one workgroup.s LDS:
+// one launch per direction replaces five to six latency-bound level launches.
+// Two 64x64 int planes in LDS ping-pong between the row and the column pass.
+
+constexpr int TAIL_MAX = 64;
+constexpr int TAIL_THREADS = 1024;
+
+struct TailArgs {
+	const int *src;  long src_ps;  int spitch;   // fwd: input plane (w0*h0) | inv: unused
+	int *dst;        long dst_ps;  int dpitch2;  // inv: output plane (w0*h0) | fwd: unused
+	int *pyr;        long pyr_ps;  int ppitch;   // Mallat pyramid
+	int nsteps;
+	int ws[DWTX_MAX_LEVELS + 2], hs[DWTX_MAX_LEVELS + 2];   // ws[0]xhs[0] is the tail's finest size
+};
+
+// forward lifting of sample pair k of a line (stride st) of length n: low and high
+__device__ __forceinline__ void tail_fwd_pair(const int *x, int st, int n, int k, int &lo, int &hi)
+{
+	const int x0 = x[2 * k * st];
+	const bool has_odd = 2 * k + 1 < n;
+	const int x1 = has_odd ? x[(2 * k + 1) * st] : 0;
+	const int xr = 2 * k + 2 < n ? x[(2 * k + 2) * st] : x0;
+	const int d = x1 - tdiv2(x0 + xr);
+	const int dl = k ? x[(2 * k - 1) * st] - tdiv2(x[(2 * k - 2) * st] + x0) : d;
+	lo = has_odd ? x0 + tdiv4(dl + d) : x0;   // odd length: last even sample passes through
+	hi = d;
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(TailArgs t)
+{
+	__shared__ int A[TAIL_MAX * TAIL_MAX];
+	__shared__ int B[TAIL_MAX * TAIL_MAX];
+	const int plane = blockIdx.x;
+	const int *src = t.src + plane * t.src_ps;
+	int *pyr = t.pyr + plane * t.pyr_ps;
+	int w = t.ws[0], h = t.hs[0];
+	for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {
+		const int y = i / w, x = i - y * w;
+		A[y * TAIL_MAX + x] = src[(long)y * t.spitch + x];
+	}
+	__syncthreads();
+	for (int s = 0; s < t.nsteps; ++s) {
+		const int w2 = t.ws[s + 1], h2 = t.hs[s + 1];
+		for (int i = threadIdx.x; i < h * w2; i += TAIL_THREADS) {   // rows: A -> B
+			const int r = i / w2, k = i - r * w2;
+			int lo, hi;
+			tail_fwd_pair(A + r * TAIL_MAX, 1, w, k, lo, hi);
+			B[r * TAIL_MAX + k] = lo;
+			if (2 * k + 1 < w)
+				B[r * TAIL_MAX + w2 + k] = hi;
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < h2 * w; i += TAIL_THREADS) {   // columns: B -> A
+			const int j = i / w, c = i - j * w;
+			int lo, hi;
+			tail_fwd_pair(B + c, TAIL_MAX, h, j, lo, hi);
+			A[j * TAIL_MAX + c] = lo;
+			if (2 * j + 1 < h)
+				A[(h2 + j) * TAIL_MAX + c] = hi;
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {    // detail subbands out
+			const int y = i / w, x = i - y * w;
+			if (y >= h2 || x >= w2)
+				pyr[(long)y * t.ppitch + x] = A[y * TAIL_MAX + x];
+		}
+		w = w2;
+		h = h2;
+	}
+	for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {        // root LL
+		const int y = i / w, x = i - y * w;
+		pyr[(long)y * t.ppitch + x] = A[y * TAIL_MAX + x];
+	}
+}
+
+// inverse lifting: samples 2k and 2k+1 of a line from its low half s[] and high half d[]
+__device__ __forceinline__ void tail_inv_pair(const int *s, const int *d, int st, int n, int k, int &e, int &o)
+{
+	auto even = [&](int j) {
+		const int sj = s[j * st];
+		if ((n & 1) && 2 * j == n - 1)
+			return sj;
+		const int dj = d[j * st];
+		const int dp = j ? d[(j - 1) * st] : dj;
+		return sj - tdiv4(dp + dj);
+	};
+	e = even(k);
+	o = 0;
+	if (2 * k + 1 < n) {
+		const int en = 2 * k + 2 < n ? even(k + 1) : e;
+		o = d[k * st] + tdiv2(e + en);
+	}
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(TailArgs t)
+{
+	__shared__ int A[TAIL_MAX * TAIL_MAX];
+	__shared__ int B[TAIL_MAX * TAIL_MAX];
+	const int plane = blockIdx.x;
+	const int *pyr = t.pyr + plane * t.pyr_ps;
+	int *dst = t.dst + plane * t.dst_ps;
+	{
+		const int w = t.ws[t.nsteps], h = t.hs[t.nsteps];
+		for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {
+			const int y = i / w, x = i - y * w;
+			A[y * TAIL_MAX + x] = pyr[(long)y * t.ppitch + x];
+		}
+	}
+	for (int s = t.nsteps - 1; s >= 0; --s) {
+		const int w = t.ws[s], h = t.hs[s], w2 = t.ws[s + 1], h2 = t.hs[s + 1];
+		for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {    // detail subbands in
+			const int y = i / w, x = i - y * w;
+			if (y >= h2 || x >= w2)
+				A[y * TAIL_MAX + x] = pyr[(long)y * t.ppitch + x];
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < h2 * w; i += TAIL_THREADS) {   // columns: A -> B
+			const int j = i / w, c = i - j * w;
+			int e, o;
+			tail_inv_pair(A + c, A + h2 * TAIL_MAX + c, TAIL_MAX, h, j, e, o);
+			B[(2 * j) * TAIL_MAX + c] = e;
+			if (2 * j + 1 < h)
+				B[(2 * j + 1) * TAIL_MAX + c] = o;
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < h * w2; i += TAIL_THREADS) {   // rows: B -> A
+			const int r = i / w2, k = i - r * w2;
+			int e, o;
+			tail_inv_pair(B + r * TAIL_MAX, B + r * TAIL_MAX + w2, 1, w, k, e, o);
+			A[r * TAIL_MAX + 2 * k] = e;
+			if (2 * k + 1 < w)
+				A[r * TAIL_MAX + 2 * k + 1] = o;
+		}
+		__syncthreads();
+	}
+	const int w = t.ws[0], h = t.hs[0];
+	for (int i = threadIdx.x; i < w * h; i += TAIL_THREADS) {
+		const int y = i / w, x = i - y * w;
+		dst[(long)y * t.dpitch2 + x] = A[y * TAIL_MAX + x];
+	}
+}
 
 // ------------------------------------------------------- pixels <-> planes ---
 
@@ -365,6 +742,20 @@ extern "C" int dwtx_pixels_from_planes(dwtx_ctx *ctx, uint8_t *pix, const int32_
 	return DWTX_OK;
 }
 
+static bool aligned_to(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
+
+// fewer rows per wave on small levels so that a few thousand waves are in flight
+static int pick_rpw(int strips_x, int h2, int nplanes)
+{
+	long waves32 = (long)strips_x * dwtx_cdiv(h2, MAX_ROWS_PER_WAVE) * nplanes;
+	int rpw = MAX_ROWS_PER_WAVE;
+	while (rpw > 4 && waves32 < 4096) {
+		rpw >>= 1;
+		waves32 <<= 1;
+	}
+	return rpw;
+}
+
 extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes)
 {
 	if (!ctx || !out || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
@@ -383,7 +774,33 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 			return DWTX_ERR_NOMEM;
 	}
 	const long full_ps = (long)W * H;
+	int tail_from = T;   // first step that runs inside the LDS tail kernel
+	for (int t = 0; t < T; ++t)
+		if (ws[t] <= TAIL_MAX && hs[t] <= TAIL_MAX) {
+			tail_from = t;
+			break;
+		}
 	for (int t = 0; t < T; ++t) {
+		if (t == tail_from) {
+			TailArgs ta;
+			ta.src = t == 0 ? in : tmp[(t - 1) & 1];
+			ta.src_ps = t == 0 ? full_ps : (long)ws[t] * hs[t];
+			ta.spitch = t == 0 ? W : ws[t];
+			ta.dst = nullptr;
+			ta.dst_ps = 0;
+			ta.dpitch2 = 0;
+			ta.pyr = out;
+			ta.pyr_ps = full_ps;
+			ta.ppitch = W;
+			ta.nsteps = T - t;
+			for (int k = 0; k <= T - t; ++k) {
+				ta.ws[k] = ws[t + k];
+				ta.hs[k] = hs[t + k];
+			}
+			hipLaunchKernelGGL(k_fwd_tail, dim3(nplanes), dim3(TAIL_THREADS), 0, ctx->stream, ta);
+			DWTX_LAUNCH_CHECK();
+			break;
+		}
 		LevelArgs a;
 		a.w = ws[t];
 		a.h = hs[t];
@@ -410,8 +827,23 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 		a.det = out;
 		a.det_ps = full_ps;
 		a.dpitch = W;
-		dim3 grid(dwtx_cdiv(a.w2, 64), dwtx_cdiv(a.h2, WAVES * ROWS_PER_WAVE), nplanes);
-		hipLaunchKernelGGL(k_fwd_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
+		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 && aligned_to(a.src, 16) &&
+			a.llpitch % 2 == 0 && a.ll_ps % 2 == 0 && aligned_to(a.ll, 8) &&
+			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
+		if (wide) {
+			LevelArgsW A;
+			A.nquads = a.w / 4;
+			const int sx = dwtx_cdiv(A.nquads, 64);
+			a.rpw = pick_rpw(sx, a.h2, nplanes);
+			A.a = a;
+			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
+			hipLaunchKernelGGL(k_fwd_level_w, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+		} else {
+			const int sx = dwtx_cdiv(a.w2, 64);
+			a.rpw = pick_rpw(sx, a.h2, nplanes);
+			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
+			hipLaunchKernelGGL(k_fwd_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
+		}
 		DWTX_LAUNCH_CHECK();
 	}
 	return DWTX_OK;
@@ -435,14 +867,40 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 			return DWTX_ERR_NOMEM;
 	}
 	const long full_ps = (long)W * H;
+	int tail_from = T;
+	for (int t = 0; t < T; ++t)
+		if (ws[t] <= TAIL_MAX && hs[t] <= TAIL_MAX) {
+			tail_from = t;
+			break;
+		}
+	if (tail_from < T) {
+		const int t = tail_from;
+		TailArgs ta;
+		ta.src = nullptr;
+		ta.src_ps = 0;
+		ta.spitch = 0;
+		ta.dst = t == 0 ? out : tmp[t & 1];
+		ta.dst_ps = t == 0 ? full_ps : (long)ws[t] * hs[t];
+		ta.dpitch2 = t == 0 ? W : ws[t];
+		ta.pyr = const_cast<int *>(in);
+		ta.pyr_ps = full_ps;
+		ta.ppitch = W;
+		ta.nsteps = T - t;
+		for (int k = 0; k <= T - t; ++k) {
+			ta.ws[k] = ws[t + k];
+			ta.hs[k] = hs[t + k];
+		}
+		hipLaunchKernelGGL(k_inv_tail, dim3(nplanes), dim3(TAIL_THREADS), 0, ctx->stream, ta);
+		DWTX_LAUNCH_CHECK();
+	}
 	// step t rebuilds the ws[t]*hs[t] plane; its output goes to tmp[t&1] (t odd: the big one)
-	for (int t = T - 1; t >= 0; --t) {
+	for (int t = tail_from - 1; t >= 0; --t) {
 		LevelArgs a;
 		a.w = ws[t];
 		a.h = hs[t];
 		a.w2 = ws[t + 1];
 		a.h2 = hs[t + 1];
-		if (t == T - 1) {
+		if (t == T - 1) {   // only without a tail: the root LL sits in the pyramid itself
 			a.src = in;
 			a.src_ps = full_ps;
 			a.spitch = W;
@@ -463,8 +921,23 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 		a.det = const_cast<int *>(in);
 		a.det_ps = full_ps;
 		a.dpitch = W;
-		dim3 grid(dwtx_cdiv(a.w2, INV_PAIRS), dwtx_cdiv(a.h2, WAVES * ROWS_PER_WAVE), nplanes);
-		hipLaunchKernelGGL(k_inv_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
+		const bool wide = a.w % 4 == 0 && a.llpitch % 4 == 0 && a.ll_ps % 4 == 0 && aligned_to(a.ll, 16) &&
+			a.spitch % 2 == 0 && a.src_ps % 2 == 0 && aligned_to(a.src, 8) &&
+			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
+		if (wide) {
+			LevelArgsW A;
+			A.nquads = a.w / 4;
+			const int sx = dwtx_cdiv(A.nquads, INV_PAIRS);
+			a.rpw = pick_rpw(sx, a.h2, nplanes);
+			A.a = a;
+			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
+			hipLaunchKernelGGL(k_inv_level_w, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+		} else {
+			const int sx = dwtx_cdiv(a.w2, INV_PAIRS);
+			a.rpw = pick_rpw(sx, a.h2, nplanes);
+			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
+			hipLaunchKernelGGL(k_inv_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
+		}
 		DWTX_LAUNCH_CHECK();
 	}
 	return DWTX_OK;
