@@ -89,7 +89,6 @@ struct Work {
 	// per token
 	unsigned *tok_run;          // [n][TS]
 	unsigned char *tok_flag;    // [n][TS]
-	unsigned char *tok_ord;     // [n][TS]
 	// per chunk
 	unsigned char *sublut;      // [n][NCS*64][32]
 	unsigned char *lut;         // [n][NCS][32]
@@ -98,6 +97,7 @@ struct Work {
 	unsigned char *group_entry; // [n][NGS]
 	unsigned long long *chunk_bits;    // [n][NCS]
 	unsigned long long *chunk_base;    // [n][NCS]
+	unsigned long long *lane_bits;     // [n][NCS*64] bit offset of each lane's 64 tokens inside its chunk
 	long ES, TS, NCS, NGS;
 	int NT;
 };
@@ -670,11 +670,22 @@ __device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long lon
 	return inc - v;
 }
 
+// The token arrays are read as coalesced 64-token rows and transposed through LDS
+// (row pitch 65 words: lane j then reads [j][t] conflict-free), because lane j
+// needs the 64 CONSECUTIVE tokens j*64 .. j*64+63 of the wave's 4096-token chunk.
+constexpr int ORD_WAVES = 2;
+
+struct OrdTile {
+	unsigned run[64][65];
+	unsigned char flag[64][68];
+};
+
 template <bool EMIT>
-__global__ __launch_bounds__(256) void k_orders(Work w, unsigned *out, long out_words)
+__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w, unsigned *out, long out_words)
 {
-	const int lane = threadIdx.x & 63;
-	const long chunk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	__shared__ OrdTile tiles[ORD_WAVES];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const long chunk = (long)blockIdx.x * ORD_WAVES + wv;
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
 	const unsigned T = I.T;
@@ -683,53 +694,50 @@ __global__ __launch_bounds__(256) void k_orders(Work w, unsigned *out, long out_
 		return;
 	const unsigned *run = w.tok_run + img * w.TS;
 	const unsigned char *flag = w.tok_flag + img * w.TS;
-	unsigned char *ord = w.tok_ord + img * w.TS;
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
 	unsigned long long *rawoff = w.seg_rawoff + (long)img * MAX_SEGS;
-	const long t0 = chunk * CHUNK + (long)lane * SUB;
-	const long t1 = min(t0 + SUB, (long)T);
+	OrdTile &tile = tiles[wv];
+	const long tbase = chunk * CHUNK;
+#pragma unroll 8
+	for (int r = 0; r < 64; ++r) {
+		const long t = tbase + r * 64 + lane;
+		const bool in = t < (long)T;
+		tile.run[r][lane] = in ? run[t] : 0u;
+		tile.flag[r][lane] = in ? flag[t] : (unsigned char)F_VOID;
+	}
+	__builtin_amdgcn_wave_barrier();   // each wave only reads back its own tile
 
-	unsigned long long bits = 0;
+	// this lane's 64 tokens start at the order recorded for (chunk entry state, sub-chunk)
+	int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
+	const long t0 = tbase + (long)lane * SUB;
+
 	if (!EMIT) {
-		int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
-		for (long t = t0; t < t1; ++t) {
-			const unsigned f = flag[t];
-			ord[t] = (unsigned char)o;
+		unsigned long long bits = 0;
+		for (int t = 0; t < SUB; ++t) {
+			const unsigned f = tile.flag[lane][t];
 			if (!(f & F_VOID)) {
-				const int top = vli_top(o, run[t]);
+				const int top = vli_top(o, tile.run[lane][t]);
 				bits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
 				o = vli_next(top);
 			}
 			if (f & F_BREAK)
-				bits += srefs[find_break_seg(btok, I.K, (unsigned)t)];
+				bits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + t))];
 		}
 		unsigned long long total;
-		wave_excl_scan64(bits, total);
+		const unsigned long long pre = wave_excl_scan64(bits, total);
+		w.lane_bits[(img * w.NCS + chunk) * 64 + lane] = pre;
 		if (lane == 0)
 			w.chunk_bits[img * w.NCS + chunk] = total;
 		return;
 	}
 
-	// EMIT: recompute this lane's bit count to find its start offset
-	for (long t = t0; t < t1; ++t) {
-		const unsigned f = flag[t];
-		if (!(f & F_VOID)) {
-			const int o = ord[t];
-			const int top = vli_top(o, run[t]);
-			bits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
-		}
-		if (f & F_BREAK)
-			bits += srefs[find_break_seg(btok, I.K, (unsigned)t)];
-	}
-	unsigned long long total;
-	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + wave_excl_scan64(bits, total);
-
+	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[(img * w.NCS + chunk) * 64 + lane];
 	// bits.h:58-78 LSB-first writer over this lane's contiguous bit range
 	unsigned *dst = out + img * out_words;
-	unsigned long long acc = 0;      // bits [wordpos*32, ...) being assembled
+	unsigned long long acc = 0;      // the word being assembled: bits at and above position `fill` are still free
 	long wordpos = (long)(pos >> 5);
-	int fill = (int)(pos & 31);      // valid low bits of acc are [fill_start..): acc holds bits at offset within word
+	int fill = (int)(pos & 31);
 	auto flush_word = [&]() {
 		if (wordpos < out_words && (unsigned)acc)
 			atomicOr(dst + wordpos, (unsigned)acc);
@@ -745,20 +753,20 @@ __global__ __launch_bounds__(256) void k_orders(Work w, unsigned *out, long out_
 		if (fill >= 32)
 			flush_word();
 	};
-	for (long t = t0; t < t1; ++t) {
-		const unsigned f = flag[t];
+	for (int t = 0; t < SUB; ++t) {
+		const unsigned f = tile.flag[lane][t];
 		if (!(f & F_VOID)) {
-			const int o = ord[t];
-			const unsigned v = run[t];
+			const unsigned v = tile.run[lane][t];
 			const int top = vli_top(o, v);
 			put(0, top - o);
 			put(1, 1);
 			put(v + (1u << o) - (1u << top), top);
 			if (f & F_HAS_SIGN)
 				put(f & F_SIGN, 1);
+			o = vli_next(top);
 		}
 		if (f & F_BREAK) {
-			const long k = find_break_seg(btok, I.K, (unsigned)t);
+			const long k = find_break_seg(btok, I.K, (unsigned)(t0 + t));
 			const unsigned long long here = ((unsigned long long)wordpos << 5) + (unsigned)fill;
 			rawoff[k] = here;
 			const unsigned n2 = srefs[k];
@@ -978,11 +986,10 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.ent_refscum = (unsigned *)(ent + o_rc);
 
 		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
-		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 2 * (size_t)n * w.TS);
+		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, (size_t)n * w.TS);
 		if (!w.tok_run || !tb)
 			return DWTX_ERR_NOMEM;
 		w.tok_flag = (unsigned char *)tb;
-		w.tok_ord = (unsigned char *)tb + (size_t)n * w.TS;
 
 		w.sublut = (unsigned char *)dwtx_scratch(ctx, SLOT_PK_LUT, (size_t)n * w.NCS * 64 * 32);
 		off = 0;
@@ -992,6 +999,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_ge = take((size_t)n * w.NGS);
 		const size_t o_cb = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
 		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
+		const size_t o_lb = take(sizeof(unsigned long long) * (size_t)n * w.NCS * 64);
 		char *ch = (char *)dwtx_scratch(ctx, SLOT_PK_CHUNK, off);
 		if (!w.sublut || !ch)
 			return DWTX_ERR_NOMEM;
@@ -1001,6 +1009,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.group_entry = (unsigned char *)(ch + o_ge);
 		w.chunk_bits = (unsigned long long *)(ch + o_cb);
 		w.chunk_base = (unsigned long long *)(ch + o_cs);
+		w.lane_bits = (unsigned long long *)(ch + o_lb);
 	}
 
 	hipStream_t s = ctx->stream;
@@ -1017,10 +1026,10 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_lut, dim3((int)((w.NCS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
-	const int cgrid = (int)((w.NCS + 3) / 4);
-	hipLaunchKernelGGL(k_orders<false>, dim3(cgrid, n), dim3(256), 0, s, w, outw, out_words);
+	const int cgrid = (int)((w.NCS + ORD_WAVES - 1) / ORD_WAVES);
+	hipLaunchKernelGGL(k_orders<false>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
-	hipLaunchKernelGGL(k_orders<true>, dim3(cgrid, n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_orders<true>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refine, dim3(egrid, n), dim3(256), 0, s, g, lin, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");

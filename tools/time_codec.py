@@ -1,0 +1,25 @@
+"""Stage timing of encode/decode on device-resident frames (development aid)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, dwt_amd
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+H = int(sys.argv[2]) if len(sys.argv) > 2 else W
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+ctx = dwt_amd.Context(0)
+pix = ctx.synth_pixels(n, H, W, C, 0, 0)
+streams, info = ctx.encode_device(pix)
+lens = ctx.stream_lengths(info)
+out, infos = ctx.decode_device(streams, lens, W, H, C)
+torch.cuda.synchronize()
+assert torch.equal(out.view(n, H, W, C), pix)
+def timed(fn, reps=5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+te = timed(lambda: ctx.encode_device(pix, out=streams, info=info))
+td = timed(lambda: ctx.decode_device(streams, lens, W, H, C, out=out))
+mp = n * W * H / 1e6
+print(f"{W}x{H}x{C} x{n}: encode {te:.2f} ms ({mp/te*1e3:.0f} Mpx/s)  decode {td:.2f} ms ({mp/td*1e3:.0f} Mpx/s)  round trip {mp/(te+td)*1e3:.0f} Mpx/s  bytes/frame {int(lens.sum())//n}")
