@@ -16,13 +16,18 @@
 //               segment the stream offset of its refinement block.  Truncated
 //               streams simply stop here; what was parsed stays valid
 //               (decode.c:204-205).
-//   k_rank      per (ring, plane): exclusive scan over 1024-coefficient tiles
-//               of the number of not-yet-significant coefficients.
-//   k_apply     one wave per tile and plane, planes descending: a coefficient
-//               that is not yet significant is pass-1 symbol #rank -> read its
-//               bit from `onebits`; a significant one is refinement bit #(index
-//               - rank) -> read it straight from the stream.
-//   k_finish    sign-magnitude -> two's complement (decode.c:102-117).
+//   k_spec/k_link/k_scan_*/k_breaks  speculative 128-bit chunk parse that lets the
+//               walker jump over stitched stretches of the stream (see below).
+//   k_hopbits   sets the symbol bits of everything the walker jumped over.
+//   k_rank + k_count  per plane, descending, on per-tile COUNTS only: first pass-1
+//               symbol index of every 1024-coefficient tile (exclusive scan of the
+//               tiles' insignificant counts) and the ones each tile gains (popcount
+//               of its slice of `onebits`).
+//   k_apply_all one wave per tile, all planes in registers: an insignificant
+//               coefficient is pass-1 symbol #rank -> bit from `onebits`; a
+//               significant one is refinement bit #(index - rank) -> read straight
+//               from the stream.  Written once, in two's complement
+//               (decode.c:102-117).
 #include "dwtx_internal.h"
 
 #include <string.h>
@@ -72,8 +77,8 @@ struct DWork {
 	int *segidx;                    // [n][3][16][MAX_PLANES] -> k+1
 	int *nonsig;                    // [n][3][16]
 	unsigned *onebits, *signbits;   // [n][BW] words
-	unsigned short *tile_sig;       // [nplanes][NT]
-	unsigned *tile_rank;            // [nplanes][NT]
+	unsigned short *tile_nonsig;    // [nplanes][NT] coefficients of the tile that are still insignificant
+	unsigned *tile_rank;            // [nplanes][MAX_PLANES][NT] insignificant coefficients before the tile, per plane
 	long BW;                        // bitmap words per image
 	int NT;
 	// speculative chunk parse (see k_spec): per 128-bit chunk of every stream
@@ -283,21 +288,36 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 // any other path that has been running for a while.  The last round records the
 // token/symbol counts and whether the exit still moved ("unjoined").
 __global__ __launch_bounds__(256) void k_link(DWork w, const unsigned char *streams, long stream_stride,
-	const unsigned short *in_exit, unsigned short *out_exit, int record)
+	const unsigned short *in_exit, unsigned short *out_exit, const unsigned short *older_exit, int last)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y, img = vs / FAM;
 	if (chunk > w.NCH)
 		return;
-	unsigned long long sym = 0;
-	unsigned tok = 0, unjoined = 1;
-	unsigned short out = 0xffff;
-	if (chunk >= 1 && chunk < w.NCH) {
-		const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
+	const long ci = vs * (w.NCH + 1) + chunk;
+	if (chunk == 0 || chunk == w.NCH) {
+		// chunk 0 has no predecessor; element NCH is the scan sentinel (its prefix = grand total)
+		if (chunk == 0)
+			out_exit[vs * w.NCH] = 0xffff;
+		w.cs[ci] = chunk == 0 ? 1ull << 62 : 0ull;
+		w.ct[ci] = 0;
+		w.cg[ci] = chunk == 0 ? 1u : 0u;
+		return;
+	}
+	const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
+	unsigned short out;
+	if (older_exit && older_exit[vs * w.NCH + chunk - 1] == in) {
+		// entered exactly as in the previous round: same path, same exit, same counts
+		out = in_exit[vs * w.NCH + chunk];
+	} else {
+		unsigned long long sym = 1ull << 62;   // a dead path is never hopped over
+		unsigned tok = 0;
+		out = 0xffff;
 		if (in != 0xffff) {
 			const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
 			int off = in & 0xff, o = in >> 8;
 			bool dead = false;
+			unsigned long long acc = 0;
 			while (off < CH_BITS) {
 				int len, next;
 				unsigned run, neg;
@@ -308,25 +328,19 @@ __global__ __launch_bounds__(256) void k_link(DWork w, const unsigned char *stre
 				off += len;
 				o = next;
 				++tok;
-				sym += (unsigned long long)run + 1ull;
+				acc += (unsigned long long)run + 1ull;
 			}
 			if (!dead) {
 				out = (unsigned short)((off - CH_BITS) | (o << 8));
-				unjoined = out == in_exit[vs * w.NCH + chunk] ? 0u : 1u;
+				sym = acc;
 			}
 		}
+		w.cs[ci] = sym;
+		w.ct[ci] = tok;
 	}
-	if (out == 0xffff)
-		sym = 1ull << 62;   // never hopped over
-	if (chunk < w.NCH)
-		out_exit[vs * w.NCH + chunk] = out;
-	else
-		sym = 0, tok = 0, unjoined = 0;   // sentinel element: its exclusive prefix is the grand total
-	if (!record)
-		return;
-	w.cs[vs * (w.NCH + 1) + chunk] = sym;
-	w.ct[vs * (w.NCH + 1) + chunk] = tok;
-	w.cg[vs * (w.NCH + 1) + chunk] = unjoined;
+	out_exit[vs * w.NCH + chunk] = out;
+	if (last)   // "unjoined": the exit still moved in the final round
+		w.cg[ci] = (out == 0xffff || out != in_exit[vs * w.NCH + chunk]) ? 1u : 0u;
 }
 
 // three-kernel exclusive scan of (cs, ct, cg) over the NCH+1 elements of every image
@@ -852,7 +866,11 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 }
 
 // ------------------------------------------------------------------ k_rank ---
-// per (plane-of-image, ring): exclusive scan over tiles of the not-yet-significant count
+// Which pass-1 symbol a coefficient is depends on how many coefficients before
+// it are still insignificant.  Per tile that count only needs the symbol bitmaps:
+// for planes descending, k_rank scans the tiles' insignificant counts of a ring
+// (-> first symbol index of every tile at this plane) and k_count subtracts the
+// ones the plane finds in each tile.  No coefficient is touched yet.
 
 __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 {
@@ -864,20 +882,15 @@ __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 	if (w.info[img].status || !w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p])
 		return;
 	const int t0 = g.tile_first[l], nt = g.tile_first[l + 1] - t0;
-	const long ring = (long)g.pixels[l + 1] - g.pixels[l];
-	const unsigned short *sig = w.tile_sig + (long)plane * w.NT + t0;
-	unsigned *rank = w.tile_rank + (long)plane * w.NT + t0;
+	const unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + t0;
+	unsigned *rank = w.tile_rank + ((long)plane * MAX_PLANES + p) * w.NT + t0;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	if (threadIdx.x == 0)
 		carry = 0;
 	__syncthreads();
 	for (int b0 = 0; b0 < nt; b0 += 1024) {
 		const int i = b0 + threadIdx.x;
-		unsigned v = 0;
-		if (i < nt) {
-			const long left = ring - (long)i * TILE;
-			v = (unsigned)(left < TILE ? left : TILE) - sig[i];
-		}
+		const unsigned v = i < nt ? ns[i] : 0u;
 		unsigned inc = v;
 		for (int o = 1; o < 64; o <<= 1) {
 			const unsigned t = __shfl_up(inc, o);
@@ -903,13 +916,10 @@ __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 	}
 }
 
-// ----------------------------------------------------------------- k_apply ---
-
-__global__ __launch_bounds__(256) void k_apply(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
-	int *lin, int p)
+// ones among the tile's symbols at plane p = popcount of its slice of the bitmap
+__global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 {
-	const int lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
 	const int plane = blockIdx.y;
 	if (tile >= w.NT)
 		return;
@@ -922,64 +932,112 @@ __global__ __launch_bounds__(256) void k_apply(UnpackGeom g, DWork w, const unsi
 	const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
 	if (!k1)
 		return;
-	const int k = k1 - 1;
+	unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + tile;
+	const unsigned n = *ns;
+	if (!n)
+		return;
+	const unsigned *one = w.onebits + img * w.BW;
+	const unsigned long long a = w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] +
+		w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
+	const unsigned long long e = a + n;   // bits [a, e)
+	unsigned ones = 0;
+	for (unsigned long long wi = a >> 5; wi <= (e - 1) >> 5; ++wi) {
+		unsigned m = one[wi];
+		if (wi == a >> 5)
+			m &= ~0u << (a & 31);
+		if (wi == (e - 1) >> 5 && (e & 31))
+			m &= (1u << (e & 31)) - 1u;
+		ones += (unsigned)__builtin_popcount(m);
+	}
+	*ns = (unsigned short)(n - ones);
+}
+
+// --------------------------------------------------------------- k_apply_all ---
+// One wave per tile, all planes in registers: 1024 coefficients start at zero;
+// for every plane (descending) an insignificant coefficient reads pass-1 symbol
+// #(tile rank + its position among the insignificant ones) from the bitmap, a
+// significant one reads refinement bit #(index in ring - that count) straight
+// from the stream.  The tile is written once, already in two's complement
+// (decode.c:102-117 process()).
+
+__global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
+{
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int plane = blockIdx.y;
+	if (tile >= w.NT)
+		return;
+	const int img = plane / g.C, c = plane - img * g.C;
+	const DecInfo &I = w.info[img];
+	if (I.status)
+		return;
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
 	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
-	unsigned *v32 = (unsigned *)lin + (long)plane * g.lin_stride;
 	const unsigned *one = w.onebits + img * w.BW;
 	const unsigned *sgn = w.signbits + img * w.BW;
 	const unsigned *stream = (const unsigned *)(streams + img * stream_stride);
-	const unsigned long long sym0 = w.seg_symbase[(long)img * MAX_SEGS + k];
-	const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
-	const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
-	unsigned rank = w.tile_rank[(long)plane * w.NT + tile];   // not-yet-significant coefficients before this tile
 	const unsigned long long below = (1ull << lane) - 1ull;
-	unsigned newsig = 0;
+	unsigned v[ROWS];
+#pragma unroll
+	for (int r = 0; r < ROWS; ++r)
+		v[r] = 0;
+	for (int p = I.planes[c] - 1; p >= 0; --p) {
+		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
+		if (!k1)
+			continue;
+		const int k = k1 - 1;
+		const unsigned long long sym0 = w.seg_symbase[(long)img * MAX_SEGS + k];
+		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
+		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
+		unsigned rank = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const long i = base + r * 64 + lane;
+			const bool in = i < ring1;
+			const bool was_sig = in && (v[r] & 0x7fffffffu) != 0;
+			const unsigned long long nm = __ballot(in && !was_sig);
+			const unsigned r1 = rank + (unsigned)__builtin_popcountll(nm & below);
+			if (in && !was_sig) {
+				const unsigned long long pos = sym0 + r1;
+				if ((one[pos >> 5] >> (pos & 31)) & 1u)
+					v[r] |= (1u << p) | (((sgn[pos >> 5] >> (pos & 31)) & 1u) << 31);
+			} else if (in) {
+				const unsigned r2 = (unsigned)(i - g.pixels[l]) - r1;   // significant coefficients before this one
+				if (r2 < n2done) {
+					const unsigned long long pos = b2 + r2;
+					v[r] |= ((stream[pos >> 5] >> (pos & 31)) & 1u) << p;
+				}
+			}
+			rank += (unsigned)__builtin_popcountll(nm);
+		}
+	}
+	int *dst = lin + (long)plane * g.lin_stride;
+#pragma unroll
 	for (int r = 0; r < ROWS; ++r) {
 		const long i = base + r * 64 + lane;
-		const bool in = i < ring1;
-		unsigned v = in ? v32[i] : 0u;
-		const bool was_sig = in && (v & 0x7fffffffu) != 0;
-		const unsigned long long nm = __ballot(in && !was_sig);
-		const unsigned r1 = rank + (unsigned)__builtin_popcountll(nm & below);
-		if (in && !was_sig) {
-			const unsigned long long pos = sym0 + r1;
-			if ((one[pos >> 5] >> (pos & 31)) & 1u) {
-				v |= 1u << p;
-				v |= ((sgn[pos >> 5] >> (pos & 31)) & 1u) << 31;
-				v32[i] = v;
-			}
-		} else if (in) {
-			const unsigned r2 = (unsigned)(i - g.pixels[l]) - r1;   // significant coefficients before this one
-			if (r2 < n2done) {
-				const unsigned long long pos = b2 + r2;
-				const unsigned bit = (stream[pos >> 5] >> (pos & 31)) & 1u;
-				if (bit)
-					v32[i] = v | (bit << p);
-			}
+		if (i < ring1) {
+			const int mag = (int)(v[r] & 0x1fffffffu);
+			dst[i] = (v[r] >> 31) ? -mag : mag;
 		}
-		newsig += (unsigned)__builtin_popcountll(__ballot(in && !was_sig && (v & 0x7fffffffu) != 0));
-		rank += (unsigned)__builtin_popcountll(nm);
 	}
-	if (lane == 0 && newsig)
-		w.tile_sig[(long)plane * w.NT + tile] += (unsigned short)newsig;
 }
 
-// decode.c:102-117 process(): sign<<31 | magnitude -> two's complement, detail rings only
-__global__ __launch_bounds__(256) void k_finish(UnpackGeom g, int *lin, int nplanes)
+// tile_nonsig starts as the tile's coefficient count
+__global__ __launch_bounds__(256) void k_tiles_init(UnpackGeom g, DWork w, int nplanes)
 {
-	const long per = g.lin_stride - g.pixels[0];
-	const long totalw = per * nplanes;
-	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totalw; i += (long)gridDim.x * blockDim.x) {
-		const long plane = i / per, off = i - plane * per;
-		unsigned *p = (unsigned *)lin + plane * g.lin_stride + g.pixels[0] + off;
-		const unsigned v = *p;
-		if (v) {
-			const int mag = (int)(v & 0x1fffffffu);
-			*p = (unsigned)((v >> 31) ? -mag : mag);
-		}
-	}
+	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+	const int plane = blockIdx.y;
+	if (tile >= w.NT || plane >= nplanes)
+		return;
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
+	const long left = (long)g.pixels[l + 1] - g.pixels[l] - (long)(tile - g.tile_first[l]) * TILE;
+	w.tile_nonsig[(long)plane * w.NT + tile] = (unsigned short)(left < TILE ? left : TILE);
 }
 
 } // namespace
@@ -1036,7 +1094,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		unsigned *bits = (unsigned *)dwtx_scratch(ctx, SLOT_UP_BITS, sizeof(unsigned) * 2 * (size_t)n * w.BW);
 		off = 0;
 		const size_t o_ts = take(sizeof(short) * (size_t)nplanes * NT);
-		const size_t o_tr = take(sizeof(unsigned) * (size_t)nplanes * NT);
+		const size_t o_tr = take(sizeof(unsigned) * (size_t)nplanes * MAX_PLANES * NT);
 		char *tiles = (char *)dwtx_scratch(ctx, SLOT_UP_TILES, off);
 		if (!small || !bits || !tiles)
 			return DWTX_ERR_NOMEM;
@@ -1049,7 +1107,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.nonsig = (int *)(small + o_ns);
 		w.onebits = bits;
 		w.signbits = bits + (size_t)n * w.BW;
-		w.tile_sig = (unsigned short *)(tiles + o_ts);
+		w.tile_nonsig = (unsigned short *)(tiles + o_ts);
 		w.tile_rank = (unsigned *)(tiles + o_tr);
 		// speculative chunk tables
 		w.NCH = (long)((stream_stride * 8 + CH_BITS - 1) / CH_BITS);
@@ -1096,10 +1154,12 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * 2 * (size_t)n * w.BW, ctx->stream));
-		DWTX_HIP(hipMemsetAsync(tiles + o_ts, 0, sizeof(short) * (size_t)nplanes * NT, ctx->stream));
 	}
 	hipStream_t s = ctx->stream;
-	DWTX_HIP(hipMemsetAsync(lin, 0, sizeof(int) * (size_t)nplanes * g.lin_stride, s));   // decode.c:177-179
+	// decode.c:177-179 zeroes everything; here the rings are written exactly once by k_apply_all, so only
+	// the root image (written by the token walker when it has any bits) needs clearing
+	DWTX_HIP(hipMemset2DAsync(lin, sizeof(int) * (size_t)g.lin_stride, 0, sizeof(int) * (size_t)g.pixels[0], nplanes, s));
+	hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, nplanes);
 	{
 		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), n * FAM);
 		unsigned short *e0 = w.exitP, *e1 = w.exitQ, *e2 = spare_exit;
@@ -1108,14 +1168,15 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		// Walkers enter a chunk in state exitP[chunk-1] and leave it in state exitQ[chunk].
 		unsigned short *bufs[3] = { e0, e1, e2 };
 		int cur = 0;
-		for (int r = 1; r < LINK_ROUNDS; ++r) {
-			const int nxt = (cur + 1) % 3;
-			hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt], 0);
-			cur = nxt;
+		for (int r = 1; r <= LINK_ROUNDS; ++r) {
+			const int nxt = (cur + 1) % 3, old = (cur + 2) % 3;
+			hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt],
+				r >= 2 ? bufs[old] : (const unsigned short *)nullptr, r == LINK_ROUNDS ? 1 : 0);
+			if (r < LINK_ROUNDS)
+				cur = nxt;
 		}
 		w.exitP = bufs[cur];
 		w.exitQ = bufs[(cur + 1) % 3];
-		hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, w.exitP, w.exitQ, 1);
 		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
 		hipLaunchKernelGGL(k_scan_parts, dim3(n * FAM), dim3(256), 0, s, w);
 		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
@@ -1133,10 +1194,9 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 			pmax = host_info[i].pmax;
 	for (int p = pmax - 1; p >= 0; --p) {
 		hipLaunchKernelGGL(k_rank, dim3(g.levels, nplanes), dim3(1024), 0, s, g, w, p);
-		hipLaunchKernelGGL(k_apply, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, w, streams, (long)stream_stride,
-			lin, p);
+		hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, p);
 	}
-	hipLaunchKernelGGL(k_finish, dim3(2048), dim3(256), 0, s, g, lin, nplanes);
+	hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, w, streams, (long)stream_stride, lin);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
