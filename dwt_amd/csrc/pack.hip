@@ -82,6 +82,7 @@ struct Work {
 	unsigned *seg_refs;         // [n][MAX_SEGS]
 	unsigned long long *seg_rawoff; // [n][MAX_SEGS] bit offset of the segment's refinement block
 	unsigned *brk_tok;          // [n][MAX_SEGS] token index of the segment's break slot
+	int *segidx;                // [n][3][16][MAX_PLANES] -> k+1 of the segment coding (channel, level, plane)
 	// per entry
 	unsigned short *ent_ones, *ent_zeros, *ent_refs, *ent_tz;   // [n][ES]
 	unsigned *ent_tokbase;      // [n][ES+1]
@@ -140,34 +141,35 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const long ring0 = g.pixels[l], ring1 = g.pixels[l + 1];
 	const long base = ring0 + (long)(tile - g.tile_first[l]) * TILE;
 	const int *src = lin + plane * g.total;
-	int cnt[NCUM];
-#pragma unroll
-	for (int p = 0; p < NCUM; ++p)
-		cnt[p] = 0;
+	unsigned m[ROWS];
 	unsigned mx = 0;
+	int valid = 0;
+#pragma unroll
 	for (int r = 0; r < ROWS; ++r) {
 		const long i = base + r * 64 + lane;
 		const bool in = i < ring1;
 		const int v = in ? src[i] : 0;
-		const unsigned m = in ? (unsigned)(v < 0 ? -v : v) : 0xffffffffu;   // out-of-ring lanes count nowhere
-		mx |= in ? m : 0u;
-#pragma unroll
-		for (int p = 0; p < NCUM; ++p)
-			cnt[p] += __builtin_popcountll(__ballot(m < (1u << p)));
+		m[r] = in ? (unsigned)(v < 0 ? -v : v) : 0xffffffffu;   // out-of-ring lanes count nowhere
+		mx |= in ? m[r] : 0u;
+		valid += __builtin_popcountll(__ballot(in));
 	}
-	unsigned short *out = w.cum + ((long)plane * w.NT + tile) * NCUM;
-	if (lane < NCUM) {
-		int mine = 0;
-#pragma unroll
-		for (int p = 0; p < NCUM; ++p)
-			mine = lane == p ? cnt[p] : mine;
-		out[lane] = (unsigned short)mine;
-	}
-	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
 	for (int o = 32; o; o >>= 1)
 		mx |= __shfl_xor(mx, o);
+	// bits needed by the largest magnitude of the tile: cum[p] = valid for every p >= that
+	const int top = mx ? ilog2u(mx) + 1 : 0;
+	int mine = valid;
+	for (int p = 0; p < top; ++p) {
+		int c = 0;
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r)
+			c += __builtin_popcountll(__ballot(m[r] < (1u << p)));
+		mine = lane == p ? c : mine;
+	}
+	if (lane < NCUM)
+		w.cum[((long)plane * w.NT + tile) * NCUM + lane] = (unsigned short)mine;
+	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
 	if (lane == 0 && mx)
-		atomicMax(w.planes_dev + plane, ilog2u(mx) + 1);
+		atomicMax(w.planes_dev + plane, top);
 }
 
 // ------------------------------------------------------------------ k_plan ---
@@ -264,11 +266,15 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 	// plane 0 of an all-zero ring yields, so p is clamped to 0 there.
 	int *sd = w.seg_desc + (long)img * MAX_SEGS;
 	int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	int *sx = w.segidx + (long)img * 48 * MAX_PLANES;
+	for (int i = 0; i < 48 * MAX_PLANES; ++i)
+		sx[i] = 0;
 	int K = 0, E = 0;
 	auto add = [&](int c, int l, int p) {
 		if (K >= MAX_SEGS)
 			return;
 		sd[K] = c | (l << 4) | ((p < 0 ? 0 : p) + 1) << 8;
+		sx[(c * 16 + l) * MAX_PLANES + (p < 0 ? 0 : p)] = K + 1;
 		eb[K] = E;
 		E += g.tile_first[l + 1] - g.tile_first[l];
 		++K;
@@ -406,60 +412,78 @@ __global__ __launch_bounds__(1024) void k_entries(PackGeom g, Work w)
 }
 
 // ---------------------------------------------------------------- k_tokens ---
+// One wave per 1024-coefficient tile, all planes: the tile is read once into
+// registers, then every plane that codes it classifies the same 16 rows.
 
 __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restrict__ lin, Work w)
 {
 	const int lane = threadIdx.x & 63;
-	const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int img = blockIdx.y;
-	const ImgInfo &I = w.info[img];
-	if (e >= I.E)
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int plane = blockIdx.y;
+	if (tile >= w.NT)
 		return;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int k = seg_of_entry(eb, I.K, e);
-	int c, l, p;
-	seg_unpack(w.seg_desc[(long)img * MAX_SEGS + k], c, l, p);
-	const int j = e - eb[k];
+	const int img = plane / g.C, c = plane - img * g.C;
+	const ImgInfo &I = w.info[img];
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
+	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
-	const int *src = lin + (long)(img * g.C + c) * g.total;
-	unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
+	const int *src = lin + (long)plane * g.total;
+	unsigned m[ROWS];       // magnitude, bit 31 = negative
+	bool in[ROWS];
+#pragma unroll
+	for (int r = 0; r < ROWS; ++r) {
+		const long i = base + r * 64 + lane;
+		in[r] = i < ring1;
+		const int v = in[r] ? src[i] : 0;
+		m[r] = (unsigned)(v < 0 ? -v : v) | (v < 0 ? 0x80000000u : 0u);
+	}
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int *sx = w.segidx + ((long)img * 48 + c * 16 + l) * MAX_PLANES;
 	unsigned *tok_run = w.tok_run + img * w.TS;
 	unsigned char *tok_flag = w.tok_flag + img * w.TS;
 	const unsigned long long below = (1ull << lane) - 1ull;
-	unsigned pending = 0;   // zeros since the last one of this tile (uniform)
-	for (int r = 0; r < ROWS; ++r) {
-		const long i = base + r * 64 + lane;
-		const bool in = i < ring1;
-		const int v = in ? src[i] : 0;
-		const unsigned m = (unsigned)(v < 0 ? -v : v);
-		const bool refine = in && (m >> (p + 1)) != 0;
-		const bool one = in && !refine && ((m >> p) & 1u);
-		const bool zero = in && !refine && !one;
-		const unsigned long long om = __ballot(one), zm = __ballot(zero);
-		if (one) {
-			const unsigned long long prev = om & below;
-			unsigned run;
-			if (prev) {
-				const int hb = 63 - __builtin_clzll(prev);
-				run = (unsigned)__builtin_popcountll(zm & below & ~((2ull << hb) - 1ull));
-			} else {
-				run = pending + (unsigned)__builtin_popcountll(zm & below);
+	const int pstart = I.planes[c] > 0 ? I.planes[c] - 1 : 0;
+	for (int p = pstart; p >= 0; --p) {
+		const int k1 = sx[p];
+		if (!k1)
+			continue;
+		const int e = eb[k1 - 1] + j;
+		unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
+		unsigned pending = 0;   // zeros since the last one of this tile (uniform)
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const unsigned mag = m[r] & 0x7fffffffu;
+			const bool refine = in[r] && (mag >> (p + 1)) != 0;
+			const bool one = in[r] && !refine && ((mag >> p) & 1u);
+			const bool zero = in[r] && !refine && !one;
+			const unsigned long long om = __ballot(one), zm = __ballot(zero);
+			if (one) {
+				const unsigned long long prev = om & below;
+				unsigned run;
+				if (prev) {
+					const int hb = 63 - __builtin_clzll(prev);
+					run = (unsigned)__builtin_popcountll(zm & below & ~((2ull << hb) - 1ull));
+				} else {
+					run = pending + (unsigned)__builtin_popcountll(zm & below);
+				}
+				const unsigned idx = tb + (unsigned)__builtin_popcountll(prev);
+				tok_run[idx] = run;
+				tok_flag[idx] = (unsigned char)(F_HAS_SIGN | ((m[r] >> 31) ? F_SIGN : 0));
 			}
-			const unsigned idx = tb + (unsigned)__builtin_popcountll(prev);
-			tok_run[idx] = run;
-			tok_flag[idx] = (unsigned char)(F_HAS_SIGN | (v < 0 ? F_SIGN : 0));
+			if (om) {
+				const int last = 63 - __builtin_clzll(om);
+				pending = last == 63 ? 0u : (unsigned)__builtin_popcountll(zm >> (last + 1));
+				tb += (unsigned)__builtin_popcountll(om);
+			} else {
+				pending += (unsigned)__builtin_popcountll(zm);
+			}
 		}
-		if (om) {
-			const int last = 63 - __builtin_clzll(om);
-			pending = last == 63 ? 0u : (unsigned)__builtin_popcountll(zm >> (last + 1));
-			tb += (unsigned)__builtin_popcountll(om);
-		} else {
-			pending += (unsigned)__builtin_popcountll(zm);
-		}
+		if (lane == 0)
+			w.ent_tz[img * w.ES + e] = (unsigned short)pending;
 	}
-	if (lane == 0)
-		w.ent_tz[img * w.ES + e] = (unsigned short)pending;
 }
 
 // ----------------------------------------------------------------- k_carry ---
@@ -843,60 +867,77 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 // ---------------------------------------------------------------- k_refine ---
 // encode.c:84-93 second pass: raw magnitude bits of already-significant
 // coefficients, in coefficient order.  The k-th refinement coefficient of the
-// segment owns bit (segment block offset + k).
+// segment owns bit (segment block offset + k).  One wave per tile, all planes,
+// the tile's rows held in registers; the bits of one (tile, plane) are compacted
+// through an LDS staging row and merged into the stream with atomicOr.
 
 __global__ __launch_bounds__(256) void k_refine(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words)
 {
 	__shared__ unsigned stage[4][TILE / 32 + 2];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int e = blockIdx.x * 4 + wv;
-	const int img = blockIdx.y;
+	const int tile = blockIdx.x * 4 + wv;
+	const int plane = blockIdx.y;
+	if (tile >= w.NT)
+		return;
+	const int img = plane / g.C, c = plane - img * g.C;
 	const ImgInfo &I = w.info[img];
-	if (e >= I.E)
-		return;
-	const unsigned nref = w.ent_refs[img * w.ES + e];
-	if (!nref)
-		return;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int k = seg_of_entry(eb, I.K, e);
-	int c, l, p;
-	seg_unpack(w.seg_desc[(long)img * MAX_SEGS + k], c, l, p);
-	const int j = e - eb[k];
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
+	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
-	const int *src = lin + (long)(img * g.C + c) * g.total;
-	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
-	const unsigned long long bit0 = w.seg_rawoff[(long)img * MAX_SEGS + k] + (refscum[e] - refscum[eb[k]]);
-	unsigned *st = stage[wv];
-	if (lane < TILE / 32 + 2)
-		st[lane] = 0;
-	// each wave only touches its own stage row; wave-level ordering suffices
-	__builtin_amdgcn_wave_barrier();
-	const int shift = (int)(bit0 & 31);
-	const unsigned long long below = (1ull << lane) - 1ull;
-	unsigned done = 0;
+	const int *src = lin + (long)plane * g.total;
+	unsigned m[ROWS];
+	bool in[ROWS];
+#pragma unroll
 	for (int r = 0; r < ROWS; ++r) {
 		const long i = base + r * 64 + lane;
-		const bool in = i < ring1;
-		const int v = in ? src[i] : 0;
-		const unsigned m = (unsigned)(v < 0 ? -v : v);
-		const bool refine = in && (m >> (p + 1)) != 0;
-		const unsigned long long rm = __ballot(refine);
-		if (refine && ((m >> p) & 1u)) {
-			const unsigned pos = (unsigned)shift + done + (unsigned)__builtin_popcountll(rm & below);
-			atomicOr(&st[pos >> 5], 1u << (pos & 31));
-		}
-		done += (unsigned)__builtin_popcountll(rm);
+		in[r] = i < ring1;
+		const int v = in[r] ? src[i] : 0;
+		m[r] = (unsigned)(v < 0 ? -v : v);
 	}
-	__builtin_amdgcn_wave_barrier();
-	__threadfence_block();
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int *sx = w.segidx + ((long)img * 48 + c * 16 + l) * MAX_PLANES;
+	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+	unsigned *st = stage[wv];
 	unsigned *dst = out + img * out_words;
-	const long w0 = (long)(bit0 >> 5);
-	const int nwords = (int)((shift + nref + 31) >> 5);
-	if (lane < nwords) {
-		const unsigned val = st[lane];
-		if (val && w0 + lane < out_words)
-			atomicOr(dst + w0 + lane, val);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (int p = I.planes[c] - 2; p >= 0; --p) {   // the top plane of a channel has nothing to refine
+		const int k1 = sx[p];
+		if (!k1)
+			continue;
+		const int k = k1 - 1;
+		const int e = eb[k] + j;
+		const unsigned nref = w.ent_refs[img * w.ES + e];
+		if (!nref)
+			continue;
+		const unsigned long long bit0 = w.seg_rawoff[(long)img * MAX_SEGS + k] + (refscum[e] - refscum[eb[k]]);
+		if (lane < TILE / 32 + 2)
+			st[lane] = 0;
+		// each wave only touches its own stage row; wave-level ordering suffices
+		__builtin_amdgcn_wave_barrier();
+		const int shift = (int)(bit0 & 31);
+		unsigned done = 0;
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const bool refine = in[r] && (m[r] >> (p + 1)) != 0;
+			const unsigned long long rm = __ballot(refine);
+			if (refine && ((m[r] >> p) & 1u)) {
+				const unsigned pos = (unsigned)shift + done + (unsigned)__builtin_popcountll(rm & below);
+				atomicOr(&st[pos >> 5], 1u << (pos & 31));
+			}
+			done += (unsigned)__builtin_popcountll(rm);
+		}
+		__builtin_amdgcn_wave_barrier();
+		const long w0 = (long)(bit0 >> 5);
+		const int nwords = (int)((shift + nref + 31) >> 5);
+		if (lane < nwords) {
+			const unsigned val = st[lane];
+			if (val && w0 + lane < out_words)
+				atomicOr(dst + w0 + lane, val);
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -956,6 +997,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_ro = take(sizeof(unsigned long long) * (size_t)n * MAX_SEGS);
 		const size_t o_bt = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
+		const size_t o_sx = take(sizeof(int) * (size_t)n * 48 * MAX_PLANES);
 		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
 		if (!w.cum || !small)
 			return DWTX_ERR_NOMEM;
@@ -966,6 +1008,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.seg_refs = (unsigned *)(small + o_sr);
 		w.seg_rawoff = (unsigned long long *)(small + o_ro);
 		w.brk_tok = (unsigned *)(small + o_bt);
+		w.segidx = (int *)(small + o_sx);
 		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
 
 		off = 0;
@@ -1020,8 +1063,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
 	hipLaunchKernelGGL(k_entries, dim3(n), dim3(1024), 0, s, g, w);
-	const int egrid = (int)((w.ES + 3) / 4);
-	hipLaunchKernelGGL(k_tokens, dim3(egrid, n), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_tokens, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry, dim3(n), dim3(1024), 0, s, g, w);
 	hipLaunchKernelGGL(k_lut, dim3((int)((w.NCS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
@@ -1030,7 +1072,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_orders<false>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
 	hipLaunchKernelGGL(k_orders<true>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
-	hipLaunchKernelGGL(k_refine, dim3(egrid, n), dim3(256), 0, s, g, lin, w, outw, out_words);
+	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
 	DWTX_HIP(hipMemcpyAsync(dev_info, w.info, sizeof(ImgInfo) * (size_t)n, hipMemcpyDeviceToDevice, s));

@@ -483,23 +483,29 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int img = blockIdx.y;
-	if (chunk >= w.NCH || chunk < 1)
-		return;
 	const int nh = w.nhops[img];
 	const unsigned *hf = w.hop_first + (long)img * w.MAX_HOPS, *hl = w.hop_last + (long)img * w.MAX_HOPS;
-	int lo = 0, hi = nh;   // records are in stream order: first h with hl[h] >= chunk
+	// records are in stream order; the search is done once per workgroup (uniform, scalar loads) for
+	// its first chunk, every thread then steps forward to its own chunk
+	const unsigned first_chunk = (unsigned)((long)blockIdx.x * blockDim.x);
+	int lo = 0, hi = nh;   // first h with hl[h] >= first_chunk
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
-		if (hl[mid] < (unsigned)chunk)
+		if (hl[mid] < first_chunk)
 			lo = mid + 1;
 		else
 			hi = mid;
 	}
+	if (chunk >= w.NCH || chunk < 1)
+		return;
+	int h = lo;
+	while (h < nh && hl[h] < (unsigned)chunk)
+		++h;
 	unsigned *one = w.onebits + img * w.BW, *sgn = w.signbits + img * w.BW;
 	const long n = w.NCH + 1;
 	ChunkWin c;
 	bool loaded = false;
-	for (int h = lo; h < nh && hf[h] <= (unsigned)chunk; ++h) {
+	for (; h < nh && hf[h] <= (unsigned)chunk; ++h) {
 		const int hs = w.hop_seg[(long)img * w.MAX_HOPS + h];
 		const int k = hs & 0xffff, vs = img * FAM + (hs >> 16);
 		if ((w.seg_desc[(long)img * MAX_SEGS + k] >> 8) == 0)
@@ -521,6 +527,9 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			off = (int)(entry & 0xff);
 			o = (int)(entry >> 8);
 		}
+		// symbol positions only grow: gather the bits of one bitmap word before touching memory
+		long cur = -1;
+		unsigned aone = 0, asgn = 0;
 		while (off < CH_BITS && left) {
 			int len, next;
 			unsigned run, neg;
@@ -529,11 +538,25 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			off += len;
 			o = next;
 			pos += run;
-			atomicOr(one + (pos >> 5), 1u << (pos & 31));
-			if (neg)
-				atomicOr(sgn + (pos >> 5), 1u << (pos & 31));
+			const long wi = (long)(pos >> 5);
+			if (wi != cur) {
+				if (aone) {
+					atomicOr(one + cur, aone);
+					if (asgn)
+						atomicOr(sgn + cur, asgn);
+				}
+				cur = wi;
+				aone = asgn = 0;
+			}
+			aone |= 1u << (pos & 31);
+			asgn |= neg << (pos & 31);
 			++pos;
 			--left;
+		}
+		if (aone) {
+			atomicOr(one + cur, aone);
+			if (asgn)
+				atomicOr(sgn + cur, asgn);
 		}
 	}
 }
