@@ -118,10 +118,15 @@ def main():
     def step():
         streams, inf = ctx.encode_device(pix, out=out, info=info)
         lens = ctx.stream_lengths(inf)
+        work = None
         if world > 1:
-            # the one exchange step of the path: lengths, then the streams, to rank 0 over RCCL/xGMI
-            gathered["streams"], gathered["lens"] = gather_streams(streams, lens, dst=0)
+            # the one exchange step of the path: lengths, then the streams, to rank 0 over RCCL/xGMI;
+            # the transfer overlaps this rank's own decode
+            gathered["streams"], gathered["lens"], work, gathered["send"] = gather_streams(streams, lens, dst=0,
+                                                                                           async_op=True)
         d, dinfos = ctx.decode_device(streams, lens, W, H, C, out=dec)
+        if work is not None:
+            work.wait()
         return streams, lens, d, dinfos
 
     def fence():
@@ -189,6 +194,14 @@ def main():
     enc_ms, _ = timed(lambda: ctx.encode_device(pix, out=out, info=info))
     dec_ms, _ = timed(lambda: ctx.decode_device(streams, lens, W, H, C, out=dec))
 
+    # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE doubled, WRITE_SIZE), collected
+    # in a separate profiling run (profiles/): the counters cannot be read from inside this process
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_lift_traffic_pmc.json")
+    if os.path.exists(tpath):
+        traffic = {"bytes_per_sample": round(json.load(open(tpath))["traffic_bytes_per_sample"], 2),
+                   "algorithmic_bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
+                   "source": "profiles/r01_lift_traffic_pmc.json (rocprofv3 --pmc, separate run of the same kernels)"}
     if rank == 0:
         total_px = world * B * W * H * args.steps
         result = {
@@ -221,7 +234,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
                 "us_per_frame": round(lift_ms * 1e3 / B, 2),
             },

@@ -10,14 +10,15 @@ def shard_frames(total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def gather_streams(streams, lens, dst=0, group=None):
+def gather_streams(streams, lens, dst=0, group=None, async_op=False):
     """Gather variable-length byte streams to rank `dst`.
 
     streams: uint8 tensor [n, stride] (row i holds lens[i] valid bytes), lens: int64 [n],
     same n on every rank.  Returns (list of per-rank uint8 tensors [n, width], int64
     tensor [world*n]) on dst and (None, lens_all) elsewhere.  Two collectives: an
     all_gather of the lengths, then one gather of rows cut to the longest stream
-    (rounded up to 8 bytes)."""
+    (rounded up to 8 bytes).  With async_op the gather runs on the collective's own stream
+    and (bufs, all_lens, work, send_buffer) is returned."""
     import torch
     import torch.distributed as dist
 
@@ -29,5 +30,8 @@ def gather_streams(streams, lens, dst=0, group=None):
     width = min(streams.shape[1], (int(all_lens.max().item()) + 7) // 8 * 8)
     mine = streams[:, :width].contiguous()
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
-    dist.gather(mine, bufs, dst=dst, group=group)
+    work = dist.gather(mine, bufs, dst=dst, group=group, async_op=async_op)
+    if async_op:
+        # the caller overlaps the transfer with its own decode and calls work.wait() at the end of the step
+        return bufs, all_lens, work, mine
     return bufs, all_lens

@@ -22,7 +22,32 @@ def case_input(rec):
     return orc.synth(rec["W"], rec["H"], rec["C"], rec["seed"], rec["kind"])
 
 
-@pytest.mark.parametrize("name", sorted(G))
+def test_config_d_16384_rgb_truncated_to_1mib(ctx):
+    """BASELINE.json configs[3]: 16384x16384 RGB, CAPACITY 1 MiB, against the reference's own output hashes."""
+    import torch
+
+    rec = G["c16384x16384_cap1MiB"]
+    W, H, Cn = rec["W"], rec["H"], rec["C"]
+    pix = ctx.synth_pixels(1, H, W, Cn, seed0=0, kind=0)
+    streams, info = ctx.encode_device(pix, capacity=rec["capacity"])
+    lens = ctx.stream_lengths(info)
+    assert int(lens[0]) == rec["dwt_len"]
+    data = streams[0, : int(lens[0])].cpu().numpy().tobytes()
+    assert sha(data) == rec["dwt_sha256"]
+    del pix
+    torch.cuda.empty_cache()
+    out, infos = ctx.decode_device(streams, lens, W, H, Cn)
+    g = orc.geometry(W, H)
+    lo = infos[0].level + 1
+    assert (g.widths[lo], g.heights[lo]) == (rec["dec_W"], rec["dec_H"])
+    h = hashlib.sha256()
+    flat = out[0, : rec["dec_W"] * rec["dec_H"] * Cn]
+    for i in range(0, flat.numel(), 1 << 27):
+        h.update(flat[i:i + (1 << 27)].cpu().numpy().tobytes())
+    assert h.hexdigest() == rec["dec_sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(k for k in G if not G[k].get("heavy")))
 def test_goldens_from_the_real_reference(ctx, name):
     rec = G[name]
     pix = case_input(rec)

@@ -30,6 +30,8 @@ SMALL = [k for k, v in G.items() if v["W"] * v["H"] <= 1024 * 1024]
 @pytest.mark.parametrize("name", sorted(G))
 def test_golden_encode_decode(name):
     rec = G[name]
+    if rec.get("heavy"):
+        pytest.skip("heavy golden (minutes of CPU): covered by the GPU test")
     if name not in SMALL and os.environ.get("DWT_FULL_GOLDEN", "1") == "0":
         pytest.skip("large golden skipped")
     pix = case_input(rec)
