@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	if (lane < NCUM)
 		w.cum[((long)plane * w.NT + tile) * NCUM + lane] = (unsigned short)mine;
 	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
-	if (lane == 0 && mx)
+	// 100k waves hammering one word per plane would serialise in L2: the value only grows, so a
+	// (possibly stale) plain read filters out all but the first few
+	if (lane == 0 && top > __hip_atomic_load(w.planes_dev + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 		atomicMax(w.planes_dev + plane, top);
 }
 
