@@ -90,6 +90,8 @@ struct Work {
 	// per token
 	unsigned *tok_run;          // [n][TS]
 	unsigned char *tok_flag;    // [n][TS]
+	unsigned char *tok_ord;     // [n][TS] VLI order each token is coded with
+	unsigned short *tok_off;    // [n][TS] bit offset inside its group of 64 tokens
 	// per chunk
 	unsigned char *sublut;      // [n][NCS*64][32]
 	unsigned char *lut;         // [n][NCS][32]
@@ -699,15 +701,19 @@ __device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long lon
 // The token arrays are read as coalesced 64-token rows and transposed through LDS
 // (row pitch 65 words: lane j then reads [j][t] conflict-free), because lane j
 // needs the 64 CONSECUTIVE tokens j*64 .. j*64+63 of the wave's 4096-token chunk.
+// Per token it records the VLI order it is coded with and its bit offset inside
+// the lane's 64 tokens (refinement blocks not counted); k_emit then writes the
+// tokens in parallel.
 constexpr int ORD_WAVES = 2;
 
 struct OrdTile {
 	unsigned run[64][65];
 	unsigned char flag[64][68];
+	unsigned char ord[64][68];
+	unsigned short off[64][66];
 };
 
-template <bool EMIT>
-__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w, unsigned *out, long out_words)
+__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
 {
 	__shared__ OrdTile tiles[ORD_WAVES];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -722,7 +728,6 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w, unsigned *out
 	const unsigned char *flag = w.tok_flag + img * w.TS;
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	unsigned long long *rawoff = w.seg_rawoff + (long)img * MAX_SEGS;
 	OrdTile &tile = tiles[wv];
 	const long tbase = chunk * CHUNK;
 #pragma unroll 8
@@ -737,77 +742,122 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w, unsigned *out
 	// this lane's 64 tokens start at the order recorded for (chunk entry state, sub-chunk)
 	int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
 	const long t0 = tbase + (long)lane * SUB;
-
-	if (!EMIT) {
-		unsigned long long bits = 0;
-		for (int t = 0; t < SUB; ++t) {
-			const unsigned f = tile.flag[lane][t];
-			if (!(f & F_VOID)) {
-				const int top = vli_top(o, tile.run[lane][t]);
-				bits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
-				o = vli_next(top);
-			}
-			if (f & F_BREAK)
-				bits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + t))];
-		}
-		unsigned long long total;
-		const unsigned long long pre = wave_excl_scan64(bits, total);
-		w.lane_bits[(img * w.NCS + chunk) * 64 + lane] = pre;
-		if (lane == 0)
-			w.chunk_bits[img * w.NCS + chunk] = total;
-		return;
-	}
-
-	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[(img * w.NCS + chunk) * 64 + lane];
-	// bits.h:58-78 LSB-first writer over this lane's contiguous bit range
-	unsigned *dst = out + img * out_words;
-	unsigned long long acc = 0;      // the word being assembled: bits at and above position `fill` are still free
-	long wordpos = (long)(pos >> 5);
-	int fill = (int)(pos & 31);
-	auto flush_word = [&]() {
-		if (wordpos < out_words && (unsigned)acc)
-			atomicOr(dst + wordpos, (unsigned)acc);
-		acc >>= 32;
-		++wordpos;
-		fill -= 32;
-	};
-	auto put = [&](unsigned v, int nb) {   // nb <= 32
-		if (nb <= 0)
-			return;
-		acc |= (unsigned long long)(nb < 32 ? v & ((1u << nb) - 1u) : v) << fill;
-		fill += nb;
-		if (fill >= 32)
-			flush_word();
-	};
+	unsigned tokbits = 0;              // bits of this lane's tokens so far
+	unsigned long long rawbits = 0;    // refinement blocks that follow break tokens of this lane
 	for (int t = 0; t < SUB; ++t) {
 		const unsigned f = tile.flag[lane][t];
+		tile.ord[lane][t] = (unsigned char)o;
+		tile.off[lane][t] = (unsigned short)tokbits;
 		if (!(f & F_VOID)) {
-			const unsigned v = tile.run[lane][t];
-			const int top = vli_top(o, v);
-			put(0, top - o);
-			put(1, 1);
-			put(v + (1u << o) - (1u << top), top);
-			if (f & F_HAS_SIGN)
-				put(f & F_SIGN, 1);
+			const int top = vli_top(o, tile.run[lane][t]);
+			tokbits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
 			o = vli_next(top);
 		}
-		if (f & F_BREAK) {
-			const long k = find_break_seg(btok, I.K, (unsigned)(t0 + t));
-			const unsigned long long here = ((unsigned long long)wordpos << 5) + (unsigned)fill;
-			rawoff[k] = here;
-			const unsigned n2 = srefs[k];
-			if (n2) {   // skip the refinement block (k_refine fills it)
-				if (fill && wordpos < out_words && (unsigned)acc)
-					atomicOr(dst + wordpos, (unsigned)acc);
-				const unsigned long long next = here + n2;
-				acc = 0;
-				wordpos = (long)(next >> 5);
-				fill = (int)(next & 31);
-			}
+		if (f & F_BREAK)
+			rawbits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + t))];
+	}
+	unsigned long long total;
+	const unsigned long long pre = wave_excl_scan64(tokbits + rawbits, total);
+	w.lane_bits[(img * w.NCS + chunk) * 64 + lane] = pre;
+	if (lane == 0)
+		w.chunk_bits[img * w.NCS + chunk] = total;
+	__builtin_amdgcn_wave_barrier();
+	unsigned char *ord = w.tok_ord + img * w.TS;
+	unsigned short *off = w.tok_off + img * w.TS;
+#pragma unroll 8
+	for (int r = 0; r < 64; ++r) {
+		const long t = tbase + r * 64 + lane;
+		if (t < (long)T) {
+			ord[t] = tile.ord[r][lane];
+			off[t] = tile.off[r][lane];
 		}
 	}
-	if (fill && wordpos < out_words && (unsigned)acc)
-		atomicOr(dst + wordpos, (unsigned)acc);
+}
+
+// ------------------------------------------------------------------ k_emit ---
+// bits.h:58-78: one lane per token.  The token's position is chunk base + its
+// lane-group's offset + its own offset (+ the refinement blocks of earlier break
+// tokens of the same group); its at most 62 code bits go out with atomicOr.
+
+constexpr int COMB = 192;   // words: 64 tokens of up to 62 bits, plus slack
+
+__global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_words)
+{
+	__shared__ unsigned comb[4][COMB];
+	const int lane = threadIdx.x & 63;
+	const long group = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 64 consecutive tokens
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const unsigned T = I.T;
+	if (group * SUB >= (long)T)
+		return;
+	const long t = group * SUB + lane;
+	const bool in = t < (long)T;
+	const unsigned f = in ? w.tok_flag[img * w.TS + t] : F_VOID;
+	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
+	const long chunk = group >> 6;
+	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[img * w.NCS * 64 + group] +
+		(in ? w.tok_off[img * w.TS + t] : 0);
+	// break tokens are followed by their segment's refinement block: later tokens of the group move up
+	unsigned long long bm = __ballot(in && (f & F_BREAK));
+	long myseg = -1;
+	while (bm) {
+		const int j = __builtin_ctzll(bm);
+		bm &= bm - 1;
+		const long k = find_break_seg(btok, I.K, (unsigned)(group * SUB + j));
+		if (lane > j)
+			pos += srefs[k];
+		if (lane == j)
+			myseg = k;
+	}
+	unsigned long long code = 0;
+	int len = 0;
+	if (!(f & F_VOID)) {
+		const int o = w.tok_ord[img * w.TS + t];
+		const unsigned v = w.tok_run[img * w.TS + t];
+		const int top = vli_top(o, v);
+		const int z = top - o;
+		code = (1ull << z) | ((unsigned long long)(v + (1u << o) - (1u << top)) << (z + 1));
+		len = z + 1 + top;
+		if (f & F_HAS_SIGN) {
+			code |= (unsigned long long)(f & F_SIGN) << len;
+			++len;
+		}
+	}
+	if (myseg >= 0)
+		w.seg_rawoff[(long)img * MAX_SEGS + myseg] = pos + (unsigned)len;
+	// The 64 tokens of a group are adjacent in the stream (a few bits each): merge them in an LDS
+	// window of COMB words first, so each stream word costs one global atomic per wave.  Tokens
+	// pushed far away by a refinement block go to memory directly.
+	unsigned *cw = comb[threadIdx.x >> 6];
+	for (int i = lane; i < COMB; i += 64)
+		cw[i] = 0;
+	const long wbase = (long)(__shfl(pos, 0) >> 5);
+	__builtin_amdgcn_wave_barrier();
+	unsigned *dst = out + img * out_words;
+	if (len) {
+		const long w0 = (long)(pos >> 5);
+		const int sh = (int)(pos & 31);
+		const unsigned long long lo = code << sh;
+		const unsigned part[3] = { (unsigned)lo, (unsigned)(lo >> 32), sh ? (unsigned)(code >> (64 - sh)) : 0u };
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			const long wi = w0 + q;
+			if (!part[q])
+				continue;
+			if (wi - wbase < COMB)
+				atomicOr(cw + (wi - wbase), part[q]);
+			else if (wi < out_words)
+				atomicOr(dst + wi, part[q]);
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	for (int i = lane; i < COMB; i += 64) {
+		const unsigned v = cw[i];
+		if (v && wbase + i < out_words)
+			atomicOr(dst + wbase + i, v);
+	}
 }
 
 // per image: exclusive scan of chunk bit totals
@@ -1031,10 +1081,12 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.ent_refscum = (unsigned *)(ent + o_rc);
 
 		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
-		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, (size_t)n * w.TS);
+		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 4 * (size_t)n * w.TS);
 		if (!w.tok_run || !tb)
 			return DWTX_ERR_NOMEM;
-		w.tok_flag = (unsigned char *)tb;
+		w.tok_off = (unsigned short *)tb;
+		w.tok_flag = (unsigned char *)tb + 2 * (size_t)n * w.TS;
+		w.tok_ord = (unsigned char *)tb + 3 * (size_t)n * w.TS;
 
 		w.sublut = (unsigned char *)dwtx_scratch(ctx, SLOT_PK_LUT, (size_t)n * w.NCS * 64 * 32);
 		off = 0;
@@ -1071,9 +1123,9 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
 	const int cgrid = (int)((w.NCS + ORD_WAVES - 1) / ORD_WAVES);
-	hipLaunchKernelGGL(k_orders<false>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_orders, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
-	hipLaunchKernelGGL(k_orders<true>, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.NCS * 64 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
