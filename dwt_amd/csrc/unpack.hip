@@ -94,6 +94,9 @@ struct DWork {
 	unsigned *hop_entry;            // [n][MAX_HOPS] 0xffffffff = stitched run (enter at exitP[first-1]); else off | order<<8
 	unsigned *hop_ntok;             // [n][MAX_HOPS] tokens to apply (walker-parsed chunk pieces)
 	unsigned *breaks;               // [n*FAM][NCH] chunk indices whose arriving path does not rejoin, ascending
+	unsigned *todo;                 // [n*FAM][LINK_SHARDS][todo_cap] chunks to re-parse in the current link round
+	unsigned *todo_count;           // [n*FAM][LINK_SHARDS]
+	long todo_cap;
 	int *nhops;                     // [n]
 	long NCH, NB;
 	long MAX_HOPS;
@@ -287,16 +290,56 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 // a parse started r chunks earlier (at order 0) arrives with, so it agrees with
 // any other path that has been running for a while.  The last round records the
 // token/symbol counts and whether the exit still moved ("unjoined").
-__global__ __launch_bounds__(256) void k_link(DWork w, const unsigned char *streams, long stream_stride,
-	const unsigned short *in_exit, unsigned short *out_exit, const unsigned short *older_exit, int last)
+// parse chunk `ch` of virtual stream vs from the state the previous round left chunk ch-1 in
+__device__ __forceinline__ void link_parse(const DWork &w, const unsigned char *streams, long stream_stride, int vs,
+	long ch, const unsigned short *in_exit, unsigned short *out_exit, int last)
+{
+	const int img = vs / FAM;
+	const long ci = vs * (w.NCH + 1) + ch;
+	const unsigned short in = in_exit[vs * w.NCH + ch - 1];
+	unsigned long long sym = 1ull << 62;   // a dead path is never hopped over
+	unsigned tok = 0;
+	unsigned short out = 0xffff;
+	if (in != 0xffff) {
+		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
+		int off = in & 0xff, o = in >> 8;
+		bool dead = false;
+		unsigned long long acc = 0;
+		while (off < CH_BITS) {
+			int len, next;
+			unsigned run, neg;
+			if (!token_at(chunk_win(c, off), o, len, run, neg, next)) {
+				dead = true;
+				break;
+			}
+			off += len;
+			o = next;
+			++tok;
+			acc += (unsigned long long)run + 1ull;
+		}
+		if (!dead) {
+			out = (unsigned short)((off - CH_BITS) | (o << 8));
+			sym = acc;
+		}
+	}
+	w.cs[ci] = sym;
+	w.ct[ci] = tok;
+	out_exit[vs * w.NCH + ch] = out;
+	if (last)   // "unjoined": the exit still moved in the final round
+		w.cg[ci] = (out == 0xffff || out != in_exit[vs * w.NCH + ch]) ? 1u : 0u;
+}
+
+// round 1: every chunk
+__global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride,
+	const unsigned short *in_exit, unsigned short *out_exit, int last)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int vs = blockIdx.y, img = vs / FAM;
+	const int vs = blockIdx.y;
 	if (chunk > w.NCH)
 		return;
-	const long ci = vs * (w.NCH + 1) + chunk;
 	if (chunk == 0 || chunk == w.NCH) {
 		// chunk 0 has no predecessor; element NCH is the scan sentinel (its prefix = grand total)
+		const long ci = vs * (w.NCH + 1) + chunk;
 		if (chunk == 0)
 			out_exit[vs * w.NCH] = 0xffff;
 		w.cs[ci] = chunk == 0 ? 1ull << 62 : 0ull;
@@ -304,43 +347,66 @@ __global__ __launch_bounds__(256) void k_link(DWork w, const unsigned char *stre
 		w.cg[ci] = chunk == 0 ? 1u : 0u;
 		return;
 	}
-	const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
-	unsigned short out;
-	if (older_exit && older_exit[vs * w.NCH + chunk - 1] == in) {
-		// entered exactly as in the previous round: same path, same exit, same counts
-		out = in_exit[vs * w.NCH + chunk];
-	} else {
-		unsigned long long sym = 1ull << 62;   // a dead path is never hopped over
-		unsigned tok = 0;
-		out = 0xffff;
-		if (in != 0xffff) {
-			const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
-			int off = in & 0xff, o = in >> 8;
-			bool dead = false;
-			unsigned long long acc = 0;
-			while (off < CH_BITS) {
-				int len, next;
-				unsigned run, neg;
-				if (!token_at(chunk_win(c, off), o, len, run, neg, next)) {
-					dead = true;
-					break;
-				}
-				off += len;
-				o = next;
-				++tok;
-				acc += (unsigned long long)run + 1ull;
-			}
-			if (!dead) {
-				out = (unsigned short)((off - CH_BITS) | (o << 8));
-				sym = acc;
-			}
+	link_parse(w, streams, stream_stride, vs, chunk, in_exit, out_exit, last);
+}
+
+// later rounds: a chunk entered exactly as in the previous round keeps its path, exit and counts;
+// the few others go to work lists so that they are parsed on dense waves (k_link_work).  The lists
+// are sharded (by workgroup) and filled with one atomic per workgroup: a single counter would
+// serialise a hundred thousand appends in L2.
+constexpr int LINK_SHARDS = 64;
+
+__global__ __launch_bounds__(256) void k_link_mark(DWork w, const unsigned short *in_exit, unsigned short *out_exit,
+	const unsigned short *older_exit, int last)
+{
+	__shared__ unsigned wbase[4];
+	__shared__ unsigned gbase;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int vs = blockIdx.y;
+	bool parse = false;
+	if (chunk == 0) {
+		out_exit[vs * w.NCH] = 0xffff;
+	} else if (chunk < w.NCH) {
+		const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
+		if (older_exit[vs * w.NCH + chunk - 1] == in) {
+			const unsigned short out = in_exit[vs * w.NCH + chunk];
+			out_exit[vs * w.NCH + chunk] = out;
+			if (last)
+				w.cg[vs * (w.NCH + 1) + chunk] = out == 0xffff ? 1u : 0u;
+		} else {
+			parse = true;
 		}
-		w.cs[ci] = sym;
-		w.ct[ci] = tok;
 	}
-	out_exit[vs * w.NCH + chunk] = out;
-	if (last)   // "unjoined": the exit still moved in the final round
-		w.cg[ci] = (out == 0xffff || out != in_exit[vs * w.NCH + chunk]) ? 1u : 0u;
+	const unsigned long long pm = __ballot(parse);
+	if (lane == 0)
+		wbase[wv] = (unsigned)__builtin_popcountll(pm);
+	__syncthreads();
+	const int shard = blockIdx.x % LINK_SHARDS;
+	if (threadIdx.x == 0) {
+		unsigned t = 0;
+		for (int k = 0; k < 4; ++k) {
+			const unsigned c = wbase[k];
+			wbase[k] = t;
+			t += c;
+		}
+		gbase = t ? atomicAdd(w.todo_count + vs * LINK_SHARDS + shard, t) : 0u;
+	}
+	__syncthreads();
+	if (parse)
+		w.todo[((long)vs * LINK_SHARDS + shard) * w.todo_cap + gbase + wbase[wv] +
+			(unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (unsigned)chunk;
+}
+
+__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride,
+	const unsigned short *in_exit, unsigned short *out_exit, int last)
+{
+	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
+		parts = gridDim.x / LINK_SHARDS;
+	const unsigned count = w.todo_count[vs * LINK_SHARDS + shard];
+	const unsigned *list = w.todo + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
+	for (unsigned q = part * blockDim.x + threadIdx.x; q < count; q += parts * blockDim.x)
+		link_parse(w, streams, stream_stride, vs, list[q], in_exit, out_exit, last);
 }
 
 // three-kernel exclusive scan of (cs, ct, cg) over the NCH+1 elements of every image
@@ -1153,6 +1219,9 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		const size_t o_he = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
 		const size_t o_hn = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
 		const size_t o_br = take(sizeof(unsigned) * (size_t)n * FAM * w.NCH);
+		w.todo_cap = ((w.NCH + 256) / 256 + 63) / 64 * 256 + 256;   // chunks whose workgroup maps to one shard
+		const size_t o_td = take(sizeof(unsigned) * (size_t)n * FAM * 64 * w.todo_cap);
+		const size_t o_tc = take(sizeof(unsigned) * (size_t)n * FAM * 64);
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
 		if (!chunks)
@@ -1173,6 +1242,8 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.hop_entry = (unsigned *)(chunks + o_he);
 		w.hop_ntok = (unsigned *)(chunks + o_hn);
 		w.breaks = (unsigned *)(chunks + o_br);
+		w.todo = (unsigned *)(chunks + o_td);
+		w.todo_count = (unsigned *)(chunks + o_tc);
 		w.nhops = (int *)(chunks + o_nh);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
@@ -1193,8 +1264,15 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		int cur = 0;
 		for (int r = 1; r <= LINK_ROUNDS; ++r) {
 			const int nxt = (cur + 1) % 3, old = (cur + 2) % 3;
-			hipLaunchKernelGGL(k_link, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt],
-				r >= 2 ? bufs[old] : (const unsigned short *)nullptr, r == LINK_ROUNDS ? 1 : 0);
+			const int last = r == LINK_ROUNDS ? 1 : 0;
+			if (r == 1) {
+				hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt], last);
+			} else {
+				DWTX_HIP(hipMemsetAsync(w.todo_count, 0, sizeof(unsigned) * (size_t)n * FAM * LINK_SHARDS, s));
+				hipLaunchKernelGGL(k_link_mark, cg, dim3(256), 0, s, w, bufs[cur], bufs[nxt], bufs[old], last);
+				hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, n * FAM), dim3(256), 0, s, w, streams, (long)stream_stride,
+					bufs[cur], bufs[nxt], last);
+			}
 			if (r < LINK_ROUNDS)
 				cur = nxt;
 		}
