@@ -30,6 +30,7 @@
 //               (decode.c:102-117).
 #include "dwtx_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -97,6 +98,7 @@ struct DWork {
 	unsigned *todo;                 // [n*FAM][LINK_SHARDS][todo_cap] chunks to re-parse in the current link round
 	unsigned *todo_count;           // [n*FAM][LINK_SHARDS]
 	long todo_cap;
+	unsigned long long *dbg;
 	int *nhops;                     // [n]
 	long NCH, NB;
 	long MAX_HOPS;
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	const unsigned long long *s64 = (const unsigned long long *)s8;
 	// chunk i is safe to parse blindly if every token starting in it ends inside the data
 	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
+	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter();
 	long checked = -1;
 	int nhops = 0;
 	unsigned hopped = 0, walked = 0;
@@ -752,6 +755,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					const unsigned need = (unsigned)(n1 - q);
 					const int rel = (int)(br.b - ((unsigned long long)ci << CH_LOG2));
 					bool moved = false;
+					const unsigned long long tq0 = __builtin_readcyclecounter();
 					if (ci != checked) {
 						checked = ci;
 						for (int fam = 0; fam < FAM && !moved; ++fam) {
@@ -800,6 +804,8 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							}
 						}
 					}
+					const unsigned long long tq1 = __builtin_readcyclecounter();
+					t_hop += tq1 - tq0;
 					if (!moved) {
 						// parse the rest of this chunk ourselves, counting only; k_hopbits sets the bits later
 						const ChunkWin cw = chunk_load(s64, br.n64, ci);
@@ -835,6 +841,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							moved = true;
 						}
 					}
+					t_fast += __builtin_readcyclecounter() - tq1;
 					if (moved)
 						continue;
 				}
@@ -948,6 +955,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.hopped_chunks = hopped;
 	I.walked_tokens = walked;
 	I.pad = 0;
+	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; }
 	I.level = level;
 	I.nsegs = nsegs;
 	I.truncated = stop ? 1 : 0;
@@ -1166,6 +1174,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	unsigned short *spare_exit = nullptr;
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
+	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
 	w.BW = (long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 5) + 64;
 	{
