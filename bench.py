@@ -32,9 +32,14 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
-    "gray4096": (4096, 4096, 1, 8),
+    "gray4096": (4096, 4096, 1, 16),
     "rgb1080p": (1920, 1080, 3, 32),
     "rgb4096": (4096, 4096, 3, 4),
+}
+CONFIG_OF = {
+    "gray4096": "BASELINE.json configs[1] geometry",
+    "rgb1080p": "BASELINE.json configs[2] geometry",
+    "rgb4096": "BASELINE.json configs[4] geometry",
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LIFT_BYTES_PER_SAMPLE = 16      # int32 read + write, forward and inverse
@@ -219,7 +224,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{W}x{H}x{C} 8-bit synthetic smooth+noise frames, lossless, {B} frames per GPU per step "
-                            f"(BASELINE.json configs[1] geometry)",
+                            f"({CONFIG_OF[args.workload]})",
                 "frames_per_gpu": B,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of streams" if world > 1 else "1 GPU",
             },
