@@ -11,8 +11,8 @@
 //               look-ahead FIFO.  It touches no coefficient: per-(channel,
 //               level) counters of not-yet-significant coefficients tell it how
 //               many symbols each segment holds.  Output: for every pass-1
-//               symbol that is a one, a bit in `onebits` (and its sign in
-//               `signbits`) at (segment symbol base + symbol index); per
+//               symbol that is a one, two bits in `symbits` (one flag, sign)
+//               at (segment symbol base + symbol index); per
 //               segment the stream offset of its refinement block.  Truncated
 //               streams simply stop here; what was parsed stays valid
 //               (decode.c:204-205).
@@ -22,9 +22,9 @@
 //   k_rank + k_count  per plane, descending, on per-tile COUNTS only: first pass-1
 //               symbol index of every 1024-coefficient tile (exclusive scan of the
 //               tiles' insignificant counts) and the ones each tile gains (popcount
-//               of its slice of `onebits`).
+//               of its slice of `symbits`).
 //   k_apply_all one wave per tile, all planes in registers: an insignificant
-//               coefficient is pass-1 symbol #rank -> bit from `onebits`; a
+//               coefficient is pass-1 symbol #rank -> bits from `symbits`; a
 //               significant one is refinement bit #(index - rank) -> read straight
 //               from the stream.  Written once, in two's complement
 //               (decode.c:102-117).
@@ -77,7 +77,7 @@ struct DWork {
 	unsigned *seg_n2done;           // [n][MAX_SEGS]
 	int *segidx;                    // [n][3][16][MAX_PLANES] -> k+1
 	int *nonsig;                    // [n][3][16]
-	unsigned *onebits, *signbits;   // [n][BW] words
+	unsigned *symbits;              // [n][BW] words, 2 bits per pass-1 symbol (one, sign)
 	unsigned short *tile_nonsig;    // [nplanes][NT] coefficients of the tile that are still insignificant
 	unsigned *tile_rank;            // [nplanes][MAX_PLANES][NT] insignificant coefficients before the tile, per plane
 	long BW;                        // bitmap words per image
@@ -185,31 +185,29 @@ struct BitReader {
 	}
 };
 
+// Pass-1 symbols that are ones, two bits per symbol in one array: bit 2P = "symbol P is a one",
+// bit 2P+1 = its sign (P = segment symbol base + index in the segment's first pass).
 struct BitmapWriter {
-	unsigned *one, *sign;
+	unsigned *sym;
 	long cur;
-	unsigned aone, asign;
+	unsigned acc;
 	__device__ __forceinline__ void flush()
 	{
-		if (cur >= 0 && aone) {   // hop chunks add their bits to the same words later (k_hopbits)
-			atomicOr(one + cur, aone);
-			if (asign)
-				atomicOr(sign + cur, asign);
-		}
-		aone = asign = 0;
+		if (cur >= 0 && acc)   // hop chunks add their bits to the same words later (k_hopbits)
+			atomicOr(sym + cur, acc);
+		acc = 0;
 	}
 	__device__ __forceinline__ void set_one(unsigned long long pos)
 	{
-		const long wi = (long)(pos >> 5);
+		const long wi = (long)(pos >> 4);
 		if (wi != cur) {
 			flush();
 			cur = wi;
 		}
-		aone |= 1u << (pos & 31);
+		acc |= 1u << ((pos & 15) * 2);
 	}
-	__device__ __forceinline__ void set_sign(unsigned long long pos) { asign |= 1u << (pos & 31); }
+	__device__ __forceinline__ void set_sign(unsigned long long pos) { acc |= 2u << ((pos & 15) * 2); }
 };
-
 
 // ------------------------------------------------- speculative chunk parse ---
 // Under the pass-1 grammar (VLI token + sign bit, rle.h:56-64 / vli.h:67-84) the
@@ -361,9 +359,7 @@ constexpr int LINK_SHARDS = 64;
 __global__ __launch_bounds__(256) void k_link_mark(DWork w, const unsigned short *in_exit, unsigned short *out_exit,
 	const unsigned short *older_exit, int last)
 {
-	__shared__ unsigned wbase[4];
-	__shared__ unsigned gbase;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
 	bool parse = false;
@@ -381,22 +377,15 @@ __global__ __launch_bounds__(256) void k_link_mark(DWork w, const unsigned short
 		}
 	}
 	const unsigned long long pm = __ballot(parse);
-	if (lane == 0)
-		wbase[wv] = (unsigned)__builtin_popcountll(pm);
-	__syncthreads();
+	if (!pm)
+		return;   // the common case after the first rounds: nothing to re-parse in this wave
 	const int shard = blockIdx.x % LINK_SHARDS;
-	if (threadIdx.x == 0) {
-		unsigned t = 0;
-		for (int k = 0; k < 4; ++k) {
-			const unsigned c = wbase[k];
-			wbase[k] = t;
-			t += c;
-		}
-		gbase = t ? atomicAdd(w.todo_count + vs * LINK_SHARDS + shard, t) : 0u;
-	}
-	__syncthreads();
+	unsigned base = 0;
+	if (lane == 0)
+		base = atomicAdd(w.todo_count + vs * LINK_SHARDS + shard, (unsigned)__builtin_popcountll(pm));
+	base = __shfl(base, 0);
 	if (parse)
-		w.todo[((long)vs * LINK_SHARDS + shard) * w.todo_cap + gbase + wbase[wv] +
+		w.todo[((long)vs * LINK_SHARDS + shard) * w.todo_cap + base +
 			(unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (unsigned)chunk;
 }
 
@@ -546,7 +535,7 @@ __global__ __launch_bounds__(256) void k_breaks(DWork w)
 		w.breaks[(long)vs * w.NCH + cg[chunk]] = (unsigned)chunk;
 }
 
-// the tokens of every chunk (piece) the walker did not set itself -> onebits / signbits
+// the tokens of every chunk (piece) the walker did not set itself -> symbits
 __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,7 +558,7 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 	int h = lo;
 	while (h < nh && hl[h] < (unsigned)chunk)
 		++h;
-	unsigned *one = w.onebits + img * w.BW, *sgn = w.signbits + img * w.BW;
+	unsigned *sym = w.symbits + img * w.BW;
 	const long n = w.NCH + 1;
 	ChunkWin c;
 	bool loaded = false;
@@ -597,7 +586,7 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		}
 		// symbol positions only grow: gather the bits of one bitmap word before touching memory
 		long cur = -1;
-		unsigned aone = 0, asgn = 0;
+		unsigned acc = 0;
 		while (off < CH_BITS && left) {
 			int len, next;
 			unsigned run, neg;
@@ -606,26 +595,19 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			off += len;
 			o = next;
 			pos += run;
-			const long wi = (long)(pos >> 5);
+			const long wi = (long)(pos >> 4);
 			if (wi != cur) {
-				if (aone) {
-					atomicOr(one + cur, aone);
-					if (asgn)
-						atomicOr(sgn + cur, asgn);
-				}
+				if (acc)
+					atomicOr(sym + cur, acc);
 				cur = wi;
-				aone = asgn = 0;
+				acc = 0;
 			}
-			aone |= 1u << (pos & 31);
-			asgn |= neg << (pos & 31);
+			acc |= (1u | (neg << 1)) << ((pos & 15) * 2);
 			++pos;
 			--left;
 		}
-		if (aone) {
-			atomicOr(one + cur, aone);
-			if (asgn)
-				atomicOr(sgn + cur, asgn);
-		}
+		if (acc)
+			atomicOr(sym + cur, acc);
 	}
 }
 
@@ -704,10 +686,9 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	unsigned *sn2 = w.seg_n2done + (long)img * MAX_SEGS;
 	int *sidx = w.segidx + (long)img * 3 * 16 * MAX_PLANES;
 	BitmapWriter bm;
-	bm.one = w.onebits + img * w.BW;
-	bm.sign = w.signbits + img * w.BW;
+	bm.sym = w.symbits + img * w.BW;
 	bm.cur = -1;
-	bm.aone = bm.asign = 0;
+	bm.acc = 0;
 
 	unsigned cnt = 0;              // rle.h:25
 	unsigned long long symtotal = 0;
@@ -1033,13 +1014,13 @@ __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 	const unsigned n = *ns;
 	if (!n)
 		return;
-	const unsigned *one = w.onebits + img * w.BW;
-	const unsigned long long a = w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] +
-		w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
-	const unsigned long long e = a + n;   // bits [a, e)
+	const unsigned *sym = w.symbits + img * w.BW;
+	const unsigned long long a = 2 * (w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] +
+		w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile]);
+	const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
 	unsigned ones = 0;
 	for (unsigned long long wi = a >> 5; wi <= (e - 1) >> 5; ++wi) {
-		unsigned m = one[wi];
+		unsigned m = sym[wi] & 0x55555555u;
 		if (wi == a >> 5)
 			m &= ~0u << (a & 31);
 		if (wi == (e - 1) >> 5 && (e & 31))
@@ -1074,8 +1055,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
-	const unsigned *one = w.onebits + img * w.BW;
-	const unsigned *sgn = w.signbits + img * w.BW;
+	const unsigned *sym = w.symbits + img * w.BW;
 	const unsigned *stream = (const unsigned *)(streams + img * stream_stride);
 	const unsigned long long below = (1ull << lane) - 1ull;
 	unsigned v[ROWS];
@@ -1091,6 +1071,11 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
 		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
 		unsigned rank = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
+		// one word per coefficient and plane — from the symbol bitmap while insignificant, from the
+		// stream once significant.  Ranks need no loaded data, so all 16 loads are issued first.
+		unsigned word[ROWS];
+		unsigned char shift[ROWS];
+		unsigned char kind[ROWS];   // 0 nothing, 1 pass-1 symbol, 2 refinement bit
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
 			const long i = base + r * 64 + lane;
@@ -1098,18 +1083,35 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			const bool was_sig = in && (v[r] & 0x7fffffffu) != 0;
 			const unsigned long long nm = __ballot(in && !was_sig);
 			const unsigned r1 = rank + (unsigned)__builtin_popcountll(nm & below);
+			rank += (unsigned)__builtin_popcountll(nm);
+			const unsigned *ptr = sym;
+			kind[r] = 0;
+			shift[r] = 0;
 			if (in && !was_sig) {
 				const unsigned long long pos = sym0 + r1;
-				if ((one[pos >> 5] >> (pos & 31)) & 1u)
-					v[r] |= (1u << p) | (((sgn[pos >> 5] >> (pos & 31)) & 1u) << 31);
+				ptr = sym + (pos >> 4);
+				shift[r] = (unsigned char)((pos & 15) * 2);
+				kind[r] = 1;
 			} else if (in) {
 				const unsigned r2 = (unsigned)(i - g.pixels[l]) - r1;   // significant coefficients before this one
 				if (r2 < n2done) {
 					const unsigned long long pos = b2 + r2;
-					v[r] |= ((stream[pos >> 5] >> (pos & 31)) & 1u) << p;
+					ptr = stream + (pos >> 5);
+					shift[r] = (unsigned char)(pos & 31);
+					kind[r] = 2;
 				}
 			}
-			rank += (unsigned)__builtin_popcountll(nm);
+			word[r] = *ptr;
+		}
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const unsigned bits = word[r] >> shift[r];
+			if (kind[r] == 1) {
+				if (bits & 1u)
+					v[r] |= (1u << p) | ((bits & 2u) << 30);
+			} else if (kind[r] == 2) {
+				v[r] |= (bits & 1u) << p;
+			}
 		}
 	}
 	int *dst = lin + (long)plane * g.lin_stride;
@@ -1176,7 +1178,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	w.NT = NT;
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
-	w.BW = (long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 5) + 64;
+	w.BW = (long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 64;   // 2 bits per symbol
 	{
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -1189,7 +1191,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		const size_t o_n2 = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_ns = take(sizeof(int) * (size_t)n * 48);
 		char *small = (char *)dwtx_scratch(ctx, SLOT_UP_SMALL, off);
-		unsigned *bits = (unsigned *)dwtx_scratch(ctx, SLOT_UP_BITS, sizeof(unsigned) * 2 * (size_t)n * w.BW);
+		unsigned *bits = (unsigned *)dwtx_scratch(ctx, SLOT_UP_BITS, sizeof(unsigned) * (size_t)n * w.BW);
 		off = 0;
 		const size_t o_ts = take(sizeof(short) * (size_t)nplanes * NT);
 		const size_t o_tr = take(sizeof(unsigned) * (size_t)nplanes * MAX_PLANES * NT);
@@ -1203,8 +1205,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.seg_b2 = (unsigned long long *)(small + o_b2);
 		w.seg_n2done = (unsigned *)(small + o_n2);
 		w.nonsig = (int *)(small + o_ns);
-		w.onebits = bits;
-		w.signbits = bits + (size_t)n * w.BW;
+		w.symbits = bits;
 		w.tile_nonsig = (unsigned short *)(tiles + o_ts);
 		w.tile_rank = (unsigned *)(tiles + o_tr);
 		// speculative chunk tables
@@ -1256,7 +1257,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.nhops = (int *)(chunks + o_nh);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
-		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * 2 * (size_t)n * w.BW, ctx->stream));
+		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)n * w.BW, ctx->stream));
 	}
 	hipStream_t s = ctx->stream;
 	// decode.c:177-179 zeroes everything; here the rings are written exactly once by k_apply_all, so only
