@@ -42,7 +42,7 @@ constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
 constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
 constexpr int CH_BITS = 1 << CH_LOG2;
 constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
-constexpr int LINK_ROUNDS = 8;          // chunks of look-back behind every stitched entry state
+constexpr int LINK_ROUNDS = 16;         // chunks of look-back behind every stitched entry state
 constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
 
 struct UnpackGeom {
@@ -83,8 +83,8 @@ struct DWork {
 	long BW;                        // bitmap words per image
 	int NT;
 	// speculative chunk parse (see k_spec): per 128-bit chunk of every stream
-	unsigned short *exitP;          // [n][NCH]   rel | order<<8 where the path from (chunk start, order 0) leaves; 0xffff dead
-	unsigned short *exitQ;          // [n][NCH]   same for the path that arrives from exitP[chunk-1]
+	unsigned short *exitX;          // [n*FAM][NCH] rel | order<<8: state in which the chunk's recorded path leaves it; 0xffff dead
+	unsigned short *entryE;         // [n*FAM][NCH] state in which that recorded path entered (valid if == exitX[chunk-1])
 	unsigned long long *cs;         // [n][NCH+1] exclusive prefix of symbols (run+1) along the arriving paths
 	unsigned *ct;                   // [n][NCH+1] exclusive prefix of tokens
 	unsigned *cg;                   // [n][NCH+1] exclusive prefix of "arriving path does not rejoin" flags
@@ -92,11 +92,11 @@ struct DWork {
 	unsigned *part_t, *part_g;      // [n][NB]
 	int *hop_seg;                   // [n][w.MAX_HOPS]
 	unsigned *hop_first, *hop_last, *hop_q0;   // [n][w.MAX_HOPS]
-	unsigned *hop_entry;            // [n][MAX_HOPS] 0xffffffff = stitched run (enter at exitP[first-1]); else off | order<<8
+	unsigned *hop_entry;            // [n][MAX_HOPS] 0xffffffff = stitched run (enter at exitX[first-1]); else off | order<<8
 	unsigned *hop_ntok;             // [n][MAX_HOPS] tokens to apply (walker-parsed chunk pieces)
 	unsigned *breaks;               // [n*FAM][NCH] chunk indices whose arriving path does not rejoin, ascending
-	unsigned *todo;                 // [n*FAM][LINK_SHARDS][todo_cap] chunks to re-parse in the current link round
-	unsigned *todo_count;           // [n*FAM][LINK_SHARDS]
+	unsigned *todo[2];              // [n*FAM][LINK_SHARDS][todo_cap] chunks to re-parse, this round / next round
+	unsigned *todo_count[2];        // [n*FAM][LINK_SHARDS]
 	long todo_cap;
 	unsigned long long *dbg;
 	int *nhops;                     // [n]
@@ -259,7 +259,7 @@ __device__ __forceinline__ bool token_at(unsigned long long win, int o, int &len
 	return true;
 }
 
-__global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride, unsigned short *out_exit)
+__global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y, img = vs / FAM;   // virtual stream = (image, family)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 			break;
 		}
 	}
-	out_exit[vs * w.NCH + chunk] = out;
+	w.exitX[vs * w.NCH + chunk] = out;
 }
 
 // One refinement round: parse chunk i from the state in which the previous
@@ -290,21 +290,25 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 // a parse started r chunks earlier (at order 0) arrives with, so it agrees with
 // any other path that has been running for a while.  The last round records the
 // token/symbol counts and whether the exit still moved ("unjoined").
-// parse chunk `ch` of virtual stream vs from the state the previous round left chunk ch-1 in
-__device__ __forceinline__ void link_parse(const DWork &w, const unsigned char *streams, long stream_stride, int vs,
-	long ch, const unsigned short *in_exit, unsigned short *out_exit, int last)
+// Refinement by relaxation: (re-)parse chunk `ch` from the state its predecessor's recorded path
+// currently leaves in; if that moves this chunk's own exit, the successor is queued for the next
+// round.  Only the first round touches every chunk; afterwards a few percent, then a few per mille.
+// After r rounds a chunk's entry state is what a parse started r chunks earlier arrives with.
+constexpr int LINK_SHARDS = 64;   // work lists are sharded: one counter would serialise the appends in L2
+
+// returns true if the chunk's exit moved (its successor must be re-parsed)
+__device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *streams, long stream_stride, int vs, long ch)
 {
 	const int img = vs / FAM;
 	const long ci = vs * (w.NCH + 1) + ch;
-	const unsigned short in = in_exit[vs * w.NCH + ch - 1];
-	unsigned long long sym = 1ull << 62;   // a dead path is never hopped over
+	const unsigned short in = w.exitX[vs * w.NCH + ch - 1];
+	unsigned long long sym = 0;
 	unsigned tok = 0;
 	unsigned short out = 0xffff;
 	if (in != 0xffff) {
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
 		int off = in & 0xff, o = in >> 8;
 		bool dead = false;
-		unsigned long long acc = 0;
 		while (off < CH_BITS) {
 			int len, next;
 			unsigned run, neg;
@@ -315,89 +319,92 @@ __device__ __forceinline__ void link_parse(const DWork &w, const unsigned char *
 			off += len;
 			o = next;
 			++tok;
-			acc += (unsigned long long)run + 1ull;
+			sym += (unsigned long long)run + 1ull;
 		}
-		if (!dead) {
+		if (!dead)
 			out = (unsigned short)((off - CH_BITS) | (o << 8));
-			sym = acc;
-		}
 	}
+	const unsigned short old = w.exitX[vs * w.NCH + ch];
+	w.entryE[vs * w.NCH + ch] = in;
 	w.cs[ci] = sym;
 	w.ct[ci] = tok;
-	out_exit[vs * w.NCH + ch] = out;
-	if (last)   // "unjoined": the exit still moved in the final round
-		w.cg[ci] = (out == 0xffff || out != in_exit[vs * w.NCH + ch]) ? 1u : 0u;
+	w.exitX[vs * w.NCH + ch] = out;
+	return out != old && ch + 1 < w.NCH;
+}
+
+// queue chunk `ch` for the next round; one atomic per (wave, shard) instead of one per lane.
+// Every lane of the wave must call this (want = false for lanes with nothing to queue).
+__device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool want, unsigned *next_list, unsigned *next_count)
+{
+	const int lane = threadIdx.x & 63;
+	const int shard = (int)((ch >> 8) % LINK_SHARDS);
+	unsigned long long todo = __ballot(want);
+	while (todo) {
+		const int leader = __builtin_ctzll(todo);
+		const int sh = __shfl(shard, leader);
+		const unsigned long long same = __ballot(want && shard == sh) & todo;
+		unsigned base = 0;
+		if (lane == leader)
+			base = atomicAdd(next_count + vs * LINK_SHARDS + sh, (unsigned)__builtin_popcountll(same));
+		base = __shfl(base, leader);
+		if (want && shard == sh)
+			next_list[((long)vs * LINK_SHARDS + sh) * w.todo_cap + base +
+				(unsigned)__builtin_popcountll(same & ((1ull << lane) - 1ull))] = (unsigned)ch;
+		todo &= ~same;
+	}
 }
 
 // round 1: every chunk
-__global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride,
-	const unsigned short *in_exit, unsigned short *out_exit, int last)
+__global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride)
+{
+	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int vs = blockIdx.y;
+	bool moved = false;
+	if (chunk >= 1 && chunk < w.NCH)
+		moved = link_parse(w, streams, stream_stride, vs, chunk);
+	link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count[1]);
+}
+
+// later rounds: the chunks queued by the previous one
+__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur)
+{
+	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
+		parts = gridDim.x / LINK_SHARDS;
+	const unsigned count = w.todo_count[cur][vs * LINK_SHARDS + shard];
+	const unsigned *list = w.todo[cur] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
+	for (unsigned q0 = part * blockDim.x; q0 < count; q0 += parts * blockDim.x) {   // uniform trip count per wave
+		const unsigned q = q0 + threadIdx.x;
+		bool moved = false;
+		long ch = 0;
+		if (q < count) {
+			ch = list[q];
+			moved = link_parse(w, streams, stream_stride, vs, ch);
+		}
+		link_push(w, vs, ch + 1, moved, w.todo[cur ^ 1], w.todo_count[cur ^ 1]);
+	}
+}
+
+// a chunk's record is usable iff it was made from the state its predecessor now leaves in
+__global__ __launch_bounds__(256) void k_link_final(DWork w)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
 	if (chunk > w.NCH)
 		return;
-	if (chunk == 0 || chunk == w.NCH) {
-		// chunk 0 has no predecessor; element NCH is the scan sentinel (its prefix = grand total)
-		const long ci = vs * (w.NCH + 1) + chunk;
-		if (chunk == 0)
-			out_exit[vs * w.NCH] = 0xffff;
-		w.cs[ci] = chunk == 0 ? 1ull << 62 : 0ull;
+	const long ci = vs * (w.NCH + 1) + chunk;
+	if (chunk == 0 || chunk == w.NCH) {   // chunk 0 has no predecessor; element NCH is the scan sentinel
+		w.cs[ci] = 0;
 		w.ct[ci] = 0;
 		w.cg[ci] = chunk == 0 ? 1u : 0u;
 		return;
 	}
-	link_parse(w, streams, stream_stride, vs, chunk, in_exit, out_exit, last);
-}
-
-// later rounds: a chunk entered exactly as in the previous round keeps its path, exit and counts;
-// the few others go to work lists so that they are parsed on dense waves (k_link_work).  The lists
-// are sharded (by workgroup) and filled with one atomic per workgroup: a single counter would
-// serialise a hundred thousand appends in L2.
-constexpr int LINK_SHARDS = 64;
-
-__global__ __launch_bounds__(256) void k_link_mark(DWork w, const unsigned short *in_exit, unsigned short *out_exit,
-	const unsigned short *older_exit, int last)
-{
-	const int lane = threadIdx.x & 63;
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int vs = blockIdx.y;
-	bool parse = false;
-	if (chunk == 0) {
-		out_exit[vs * w.NCH] = 0xffff;
-	} else if (chunk < w.NCH) {
-		const unsigned short in = in_exit[vs * w.NCH + chunk - 1];
-		if (older_exit[vs * w.NCH + chunk - 1] == in) {
-			const unsigned short out = in_exit[vs * w.NCH + chunk];
-			out_exit[vs * w.NCH + chunk] = out;
-			if (last)
-				w.cg[vs * (w.NCH + 1) + chunk] = out == 0xffff ? 1u : 0u;
-		} else {
-			parse = true;
-		}
+	const unsigned short prev = w.exitX[vs * w.NCH + chunk - 1];
+	const bool bad = prev == 0xffff || w.entryE[vs * w.NCH + chunk] != prev || w.exitX[vs * w.NCH + chunk] == 0xffff;
+	w.cg[ci] = bad ? 1u : 0u;
+	if (bad) {   // never hopped over; keep the prefix sums small and monotone
+		w.cs[ci] = 0;
+		w.ct[ci] = 0;
 	}
-	const unsigned long long pm = __ballot(parse);
-	if (!pm)
-		return;   // the common case after the first rounds: nothing to re-parse in this wave
-	const int shard = blockIdx.x % LINK_SHARDS;
-	unsigned base = 0;
-	if (lane == 0)
-		base = atomicAdd(w.todo_count + vs * LINK_SHARDS + shard, (unsigned)__builtin_popcountll(pm));
-	base = __shfl(base, 0);
-	if (parse)
-		w.todo[((long)vs * LINK_SHARDS + shard) * w.todo_cap + base +
-			(unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] = (unsigned)chunk;
-}
-
-__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride,
-	const unsigned short *in_exit, unsigned short *out_exit, int last)
-{
-	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
-		parts = gridDim.x / LINK_SHARDS;
-	const unsigned count = w.todo_count[vs * LINK_SHARDS + shard];
-	const unsigned *list = w.todo + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
-	for (unsigned q = part * blockDim.x + threadIdx.x; q < count; q += parts * blockDim.x)
-		link_parse(w, streams, stream_stride, vs, list[q], in_exit, out_exit, last);
 }
 
 // three-kernel exclusive scan of (cs, ct, cg) over the NCH+1 elements of every image
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		int off, o;
 		if (entry == 0xffffffffu) {
 			pos += w.cs[vs * n + chunk] - w.cs[vs * n + hf[h]];
-			const unsigned short in = w.exitP[vs * w.NCH + chunk - 1];
+			const unsigned short in = w.exitX[vs * w.NCH + chunk - 1];
 			off = in & 0xff;
 			o = in >> 8;
 		} else {
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	int nsegs = 0, level = -1;
 
 	// stitched-chunk tables of this stream (k_spec / k_link / k_scan_* / k_breaks)
-	const unsigned short *exitP0 = w.exitP + (long)img * FAM * w.NCH, *exitQ0 = w.exitQ + (long)img * FAM * w.NCH;
+	const unsigned short *exitX0 = w.exitX + (long)img * FAM * w.NCH;
 	const unsigned long long *CS0 = w.cs + (long)img * FAM * (w.NCH + 1);
 	const unsigned *CT0 = w.ct + (long)img * FAM * (w.NCH + 1), *CG0 = w.cg + (long)img * FAM * (w.NCH + 1);
 	const unsigned *BR0 = w.breaks + (long)img * FAM * w.NCH;
@@ -740,18 +747,21 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					if (ci != checked) {
 						checked = ci;
 						for (int fam = 0; fam < FAM && !moved; ++fam) {
-							const unsigned ep = exitP0[fam * w.NCH + ci - 1];
+							const unsigned ep = exitX0[fam * w.NCH + ci - 1];
 							if (ep == 0xffffu || (int)(ep & 0xffu) != rel || (int)(ep >> 8) != order)
 								continue;
-							// We stand exactly where this family's path arrives from chunk ci-1, so from here on
-							// the stream IS that stitched path.  It runs unbroken up to the next unjoined chunk
-							// `re`; take all of it if the segment needs that many symbols, else binary-search
-							// the prefix sums for the last chunk that still fits.
+							// We stand exactly where this family's recorded path leaves chunk ci-1.  If chunk ci's
+							// record was made from that very state (it is not flagged), the stream IS the recorded
+							// path from here up to the next flagged chunk `nb`: take all of it if the segment
+							// needs that many symbols, else binary-search the prefix sums for the last chunk
+							// that still fits.
 							const unsigned long long *CS = CS0 + fam * (w.NCH + 1);
 							const unsigned *CT = CT0 + fam * (w.NCH + 1), *CG = CG0 + fam * (w.NCH + 1);
-							const unsigned g0 = CG[ci], gtot = CG[w.NCH];
+							const unsigned g0 = CG[ci], g1 = CG[ci + 1], gtot = CG[w.NCH];
+							if (g1 != g0)
+								continue;   // chunk ci itself was recorded from another entry state
 							const unsigned long long s0 = CS[ci];
-							long hi = g0 < gtot ? (long)BR0[fam * w.NCH + g0] : lastsafe;
+							long hi = g0 < gtot ? (long)BR0[fam * w.NCH + g0] - 1 : lastsafe;
 							hi = hi < lastsafe ? hi : lastsafe;
 							long lo = ci - 1;
 							if (hi >= ci && CS[hi + 1] - s0 <= (unsigned long long)need) {
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 								hopped += (unsigned)(lo - ci + 1);
 								q += (int)(CS[lo + 1] - s0);
 								ones += (int)(CT[lo + 1] - CT[ci]);
-								const unsigned eq = exitQ0[fam * w.NCH + lo];
+								const unsigned eq = exitX0[fam * w.NCH + lo];
 								order = (int)(eq >> 8);
 								br.b = ((unsigned long long)(lo + 1) << CH_LOG2) + (eq & 0xffu);
 								br_synced = false;
@@ -1173,7 +1183,6 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	const int nplanes = n * C;
 
 	DWork w;
-	unsigned short *spare_exit = nullptr;
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
@@ -1215,7 +1224,6 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.MAX_HOPS = 8 * MAX_SEGS + w.NCH / 8;
 		const size_t o_ep = take(sizeof(short) * (size_t)n * FAM * w.NCH);
 		const size_t o_eq = take(sizeof(short) * (size_t)n * FAM * w.NCH);
-		const size_t o_e2 = take(sizeof(short) * (size_t)n * FAM * w.NCH);
 		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * FAM * (w.NCH + 1));
 		const size_t o_ct = take(sizeof(unsigned) * (size_t)n * FAM * (w.NCH + 1));
 		const size_t o_cg = take(sizeof(unsigned) * (size_t)n * FAM * (w.NCH + 1));
@@ -1230,15 +1238,14 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		const size_t o_hn = take(sizeof(unsigned) * (size_t)n * w.MAX_HOPS);
 		const size_t o_br = take(sizeof(unsigned) * (size_t)n * FAM * w.NCH);
 		w.todo_cap = ((w.NCH + 256) / 256 + 63) / 64 * 256 + 256;   // chunks whose workgroup maps to one shard
-		const size_t o_td = take(sizeof(unsigned) * (size_t)n * FAM * 64 * w.todo_cap);
-		const size_t o_tc = take(sizeof(unsigned) * (size_t)n * FAM * 64);
+		const size_t o_td = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64 * w.todo_cap);
+		const size_t o_tc = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64);
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
 		if (!chunks)
 			return DWTX_ERR_NOMEM;
-		w.exitP = (unsigned short *)(chunks + o_ep);
-		w.exitQ = (unsigned short *)(chunks + o_eq);
-		spare_exit = (unsigned short *)(chunks + o_e2);
+		w.exitX = (unsigned short *)(chunks + o_ep);
+		w.entryE = (unsigned short *)(chunks + o_eq);
 		w.cs = (unsigned long long *)(chunks + o_cs);
 		w.ct = (unsigned *)(chunks + o_ct);
 		w.cg = (unsigned *)(chunks + o_cg);
@@ -1252,8 +1259,10 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 		w.hop_entry = (unsigned *)(chunks + o_he);
 		w.hop_ntok = (unsigned *)(chunks + o_hn);
 		w.breaks = (unsigned *)(chunks + o_br);
-		w.todo = (unsigned *)(chunks + o_td);
-		w.todo_count = (unsigned *)(chunks + o_tc);
+		w.todo[0] = (unsigned *)(chunks + o_td);
+		w.todo[1] = w.todo[0] + (size_t)n * FAM * 64 * w.todo_cap;
+		w.todo_count[0] = (unsigned *)(chunks + o_tc);
+		w.todo_count[1] = w.todo_count[0] + (size_t)n * FAM * 64;
 		w.nhops = (int *)(chunks + o_nh);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
@@ -1266,28 +1275,17 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, nplanes);
 	{
 		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), n * FAM);
-		unsigned short *e0 = w.exitP, *e1 = w.exitQ, *e2 = spare_exit;
-		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, s, w, streams, (long)stream_stride, e0);
-		// LINK_ROUNDS-1 refinement rounds rotate through three exit buffers, the last one records.
-		// Walkers enter a chunk in state exitP[chunk-1] and leave it in state exitQ[chunk].
-		unsigned short *bufs[3] = { e0, e1, e2 };
-		int cur = 0;
-		for (int r = 1; r <= LINK_ROUNDS; ++r) {
-			const int nxt = (cur + 1) % 3, old = (cur + 2) % 3;
-			const int last = r == LINK_ROUNDS ? 1 : 0;
-			if (r == 1) {
-				hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, s, w, streams, (long)stream_stride, bufs[cur], bufs[nxt], last);
-			} else {
-				DWTX_HIP(hipMemsetAsync(w.todo_count, 0, sizeof(unsigned) * (size_t)n * FAM * LINK_SHARDS, s));
-				hipLaunchKernelGGL(k_link_mark, cg, dim3(256), 0, s, w, bufs[cur], bufs[nxt], bufs[old], last);
-				hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, n * FAM), dim3(256), 0, s, w, streams, (long)stream_stride,
-					bufs[cur], bufs[nxt], last);
-			}
-			if (r < LINK_ROUNDS)
-				cur = nxt;
+		const size_t cnt_bytes = sizeof(unsigned) * (size_t)n * FAM * LINK_SHARDS;
+		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, s, w, streams, (long)stream_stride);
+		DWTX_HIP(hipMemsetAsync(w.todo_count[1], 0, cnt_bytes, s));
+		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, s, w, streams, (long)stream_stride);   // fills list 1
+		int cur = 1;
+		for (int r = 2; r <= LINK_ROUNDS; ++r) {
+			DWTX_HIP(hipMemsetAsync(w.todo_count[cur ^ 1], 0, cnt_bytes, s));
+			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, n * FAM), dim3(256), 0, s, w, streams, (long)stream_stride, cur);
+			cur ^= 1;
 		}
-		w.exitP = bufs[cur];
-		w.exitQ = bufs[(cur + 1) % 3];
+		hipLaunchKernelGGL(k_link_final, cg, dim3(256), 0, s, w);
 		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
 		hipLaunchKernelGGL(k_scan_parts, dim3(n * FAM), dim3(256), 0, s, w);
 		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
