@@ -131,14 +131,18 @@ __global__ __launch_bounds__(1024) void k_block_scan(LinGeom g, int *__restrict_
 	}
 }
 
+// Curve positions and output slots are the same for every plane: each workgroup works them out
+// once for its 1024 curve points and then copies PLANES_PER_GROUP planes.
+constexpr int PLANES_PER_GROUP = 16;
+constexpr int PTS = 4;   // curve points per thread (1024 / THREADS)
+
 template <bool INVERSE>
 __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__restrict__ blockbase,
 	int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch,
-	const int *__restrict__ missing, int C)
+	const int *__restrict__ missing, int C, int nplanes)
 {
 	__shared__ int wcount[THREADS / 64];
 	const int b = blockIdx.x;
-	const int plane = blockIdx.y;
 	const int l = level_of_block(g, b);
 	const int lb = b - g.blk_first[l];
 	const int n = g.lengths[l + 1];
@@ -149,29 +153,25 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 		return;
 	const bool full = total == npts;
 	const int w0 = g.widths[l], h0 = g.heights[l], w1 = g.widths[l + 1], h1 = g.heights[l + 1];
-	int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
-	int *pp = pyr + plane * pyr_ps;
-	int bias = 0;
-	if (INVERSE && missing) {
-		// decode.c:51-58: planes never decoded leave a dead zone; recentre non-zero values
-		const int m = missing[(plane / C) * 48 + (plane % C) * 16 + l] - 2;
-		bias = m >= 0 ? 1 << m : 0;
-	}
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int slot[PTS];
+	long offs[PTS];
+	bool ok[PTS];
 	int running = 0;
-	for (int base = 0; base < npts; base += THREADS) {
-		const int i = base + threadIdx.x;
+#pragma unroll
+	for (int q = 0; q < PTS; ++q) {
+		const int i = q * THREADS + threadIdx.x;
 		int x = 0, y = 0;
-		bool ok = false;
+		ok[q] = false;
 		if (i < npts) {
 			hilbert_d2xy(n, ((unsigned)lb << pl2) + (unsigned)i, x, y);
-			ok = x < w1 && y < h1 && (x >= w0 || y >= h0);
+			ok[q] = x < w1 && y < h1 && (x >= w0 || y >= h0);
 		}
-		int slot;
+		offs[q] = (long)y * ppitch + x;
 		if (full) {
-			slot = i;
+			slot[q] = i;
 		} else {
-			const unsigned long long mask = __ballot(ok);
+			const unsigned long long mask = __ballot(ok[q]);
 			const int before = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 			if (lane == 0)
 				wcount[wv] = __builtin_popcountll(mask);
@@ -182,18 +182,33 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 				woff += k < wv ? c : 0;
 				all += c;
 			}
-			slot = running + woff + before;
+			slot[q] = running + woff + before;
 			running += all;
 			__syncthreads();
 		}
-		if (ok) {
+	}
+	const int first = blockIdx.y * PLANES_PER_GROUP;
+	const int last = min(first + PLANES_PER_GROUP, nplanes);
+	for (int plane = first; plane < last; ++plane) {
+		int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
+		int *pp = pyr + plane * pyr_ps;
+		int bias = 0;
+		if (INVERSE && missing) {
+			// decode.c:51-58: planes never decoded leave a dead zone; recentre non-zero values
+			const int m = missing[(plane / C) * 48 + (plane % C) * 16 + l] - 2;
+			bias = m >= 0 ? 1 << m : 0;
+		}
+#pragma unroll
+		for (int q = 0; q < PTS; ++q) {
+			if (!ok[q])
+				continue;
 			if (INVERSE) {
-				int v = lp[slot];
+				int v = lp[slot[q]];
 				if (bias && v)
 					v += v < 0 ? -bias : bias;
-				pp[(long)y * ppitch + x] = v;
+				pp[offs[q]] = v;
 			} else {
-				lp[slot] = pp[(long)y * ppitch + x];
+				lp[slot[q]] = pp[offs[q]];
 			}
 		}
 	}
@@ -301,8 +316,8 @@ extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *py
 	const long ps = (long)W * H;
 	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
 		g.widths[0], g.heights[0], lin, ps, const_cast<int *>(pyr), ps, W);
-	hipLaunchKernelGGL(k_ring_copy<false>, dim3(p->nblocks, nplanes), dim3(THREADS), 0, ctx->stream,
-		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1);
+	hipLaunchKernelGGL(k_ring_copy<false>, dim3(p->nblocks, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
+		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
@@ -327,8 +342,8 @@ extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *l
 		g.widths[0], g.heights[0], const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow);
 	if (levels_out > 0) {
 		g.levels = levels_out;   // only rings 0..levels_out-1 are rebuilt
-		hipLaunchKernelGGL(k_ring_copy<true>, dim3(g.blk_first[levels_out], nplanes), dim3(THREADS), 0, ctx->stream,
-			g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C);
+		hipLaunchKernelGGL(k_ring_copy<true>, dim3(g.blk_first[levels_out], dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
+			ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes);
 	}
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;

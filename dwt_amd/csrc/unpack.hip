@@ -457,36 +457,31 @@ __global__ __launch_bounds__(256) void k_scan_local(DWork w)
 {
 	__shared__ Tri wsum[4];
 	const int img = blockIdx.y;
-	const long base = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
 	const long n = w.NCH + 1;
 	unsigned long long *cs = w.cs + img * n;
 	unsigned *ct = w.ct + img * n, *cg = w.cg + img * n;
-	Tri e[4], run = { 0, 0, 0 };
-	for (int q = 0; q < 4; ++q) {
-		const long i = base + q;
+	Tri carry = { 0, 0, 0 };
+	for (int q = 0; q < SCAN_BLOCK / 256; ++q) {   // lane-contiguous rows of 256 elements
+		const long i = (long)blockIdx.x * SCAN_BLOCK + q * 256 + threadIdx.x;
 		Tri v = { 0, 0, 0 };
 		if (i < n) {
 			v.s = cs[i];
 			v.t = ct[i];
 			v.g = cg[i];
 		}
-		e[q] = run;
-		run = tri_add(run, v);
-	}
-	Tri total;
-	const Tri pre = block_scan_tri(run, wsum, total);
-	for (int q = 0; q < 4; ++q) {
-		const long i = base + q;
+		Tri total;
+		const Tri pre = block_scan_tri(v, wsum, total);
 		if (i < n) {
-			cs[i] = pre.s + e[q].s;
-			ct[i] = pre.t + e[q].t;
-			cg[i] = pre.g + e[q].g;
+			cs[i] = carry.s + pre.s;
+			ct[i] = carry.t + pre.t;
+			cg[i] = carry.g + pre.g;
 		}
+		carry = tri_add(carry, total);
 	}
 	if (threadIdx.x == 0) {
-		w.part_s[img * w.NB + blockIdx.x] = total.s;
-		w.part_t[img * w.NB + blockIdx.x] = total.t;
-		w.part_g[img * w.NB + blockIdx.x] = total.g;
+		w.part_s[img * w.NB + blockIdx.x] = carry.s;
+		w.part_t[img * w.NB + blockIdx.x] = carry.t;
+		w.part_g[img * w.NB + blockIdx.x] = carry.g;
 	}
 }
 
@@ -520,8 +515,8 @@ __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 	const long n = w.NCH + 1;
 	const unsigned long long ps = w.part_s[img * w.NB + blockIdx.x];
 	const unsigned pt = w.part_t[img * w.NB + blockIdx.x], pg = w.part_g[img * w.NB + blockIdx.x];
-	for (int q = 0; q < 4; ++q) {
-		const long i = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + q;
+	for (int q = 0; q < SCAN_BLOCK / 256; ++q) {
+		const long i = (long)blockIdx.x * SCAN_BLOCK + q * 256 + threadIdx.x;
 		if (i < n) {
 			w.cs[img * n + i] += ps;
 			w.ct[img * n + i] += pt;
