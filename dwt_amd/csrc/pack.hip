@@ -592,30 +592,35 @@ __global__ __launch_bounds__(256) void k_lut(Work w)
 	const int img = blockIdx.y;
 	const unsigned T = w.info[img].T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
-	// both halves must stay in the loop together for the shuffles
-	const bool live = chunk < nchunks;
-	const long wave_first = chunk - half;
-	if (wave_first >= nchunks)
+	const long chunk_a = chunk - half;          // the wave's two chunks: a (lanes 0-31), a+1 (lanes 32-63)
+	if (chunk_a >= nchunks)
 		return;
+	const bool live = chunk < nchunks;
 	const unsigned *run = w.tok_run + img * w.TS;
 	const unsigned char *flag = w.tok_flag + img * w.TS;
 	unsigned char *sub = w.sublut + (img * w.NCS + chunk) * 64 * 32;
+	// lane i holds token i of a 64-token row for both chunks; bit 31 = "void" (runs are < 2^31).
+	// Tokens are broadcast with v_readlane (no LDS traffic), each half picks its own chunk's.
+	// The next row is loaded while the current one is walked.
+	auto fetch = [&](int q, unsigned &ra, unsigned &rb) {
+		const long ta = chunk_a * CHUNK + q * SUB + lane, tb = ta + CHUNK;
+		ra = ta < (long)T ? run[ta] | ((flag[ta] & F_VOID) ? 0x80000000u : 0u) : 0x80000000u;
+		rb = tb < (long)T ? run[tb] | ((flag[tb] & F_VOID) ? 0x80000000u : 0u) : 0x80000000u;
+	};
 	int o = s;
+	unsigned na, nb;
+	fetch(0, na, nb);
 	for (int q = 0; q < 64; ++q) {
 		if (live)
 			sub[q * 32 + s] = (unsigned char)o;
-		const long t0 = chunk * CHUNK + q * SUB;
-		// each lane of the half holds two consecutive tokens
-		const long ta = t0 + 2 * s, tb = ta + 1;
-		const unsigned va = live && ta < T ? run[ta] : 0u, vb = live && tb < T ? run[tb] : 0u;
-		const unsigned fa = live && ta < T ? flag[ta] : F_VOID, fb = live && tb < T ? flag[tb] : F_VOID;
-#pragma unroll 8
-		for (int t = 0; t < 32; ++t) {
-			const int srcl = half * 32 + t;
-			const unsigned v0 = __shfl(va, srcl), v1 = __shfl(vb, srcl);
-			const unsigned f0 = __shfl(fa, srcl), f1 = __shfl(fb, srcl);
-			o = vli_step(o, v0, f0 & F_VOID);
-			o = vli_step(o, v1, f1 & F_VOID);
+		const unsigned ra = na, rb = nb;
+		if (q + 1 < 64)
+			fetch(q + 1, na, nb);
+#pragma unroll
+		for (int t = 0; t < 64; ++t) {
+			const unsigned a = __builtin_amdgcn_readlane(ra, t), b = __builtin_amdgcn_readlane(rb, t);
+			const unsigned v = half ? b : a;
+			o = vli_step(o, v & 0x7fffffffu, v >> 31);
 		}
 	}
 	if (live)
