@@ -34,6 +34,7 @@
 //   k_refine  one wave per entry: refinement bits, compacted through LDS.
 #include "dwtx_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -100,7 +101,8 @@ struct Work {
 	unsigned char *group_entry; // [n][NGS]
 	unsigned long long *chunk_bits;    // [n][NCS]
 	unsigned long long *chunk_base;    // [n][NCS]
-	unsigned long long *lane_bits;     // [n][NCS*64] bit offset of each lane's 64 tokens inside its chunk
+	unsigned long long *lane_bits;     // [n][NCS*64] per 64-token group: bit offset inside its wave's chunk
+	int *slow;                         // [n] set when the fast order pass could not resolve an image
 	long ES, TS, NCS, NGS;
 	int NT;
 };
@@ -590,6 +592,8 @@ __global__ __launch_bounds__(256) void k_lut(Work w)
 	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
 	const long chunk = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
 	const int img = blockIdx.y;
+	if (!w.slow[img])
+		return;
 	const unsigned T = w.info[img].T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
 	const long chunk_a = chunk - half;          // the wave's two chunks: a (lanes 0-31), a+1 (lanes 32-63)
@@ -633,6 +637,8 @@ __global__ __launch_bounds__(256) void k_chain_groups(Work w)
 	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
 	const long group = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
 	const int img = blockIdx.y;
+	if (!w.slow[img])
+		return;
 	const unsigned T = w.info[img].T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
 	const long ngroups = (nchunks + GROUP - 1) / GROUP;
@@ -649,6 +655,8 @@ __global__ __launch_bounds__(256) void k_chain_groups(Work w)
 __global__ __launch_bounds__(1024) void k_chain_image(Work w)
 {
 	const int img = blockIdx.x;
+	if (!w.slow[img])
+		return;
 	const ImgInfo &I = w.info[img];
 	const long nchunks = ((long)I.T + CHUNK - 1) / CHUNK;
 	const long ngroups = (nchunks + GROUP - 1) / GROUP;
@@ -724,6 +732,8 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const long chunk = (long)blockIdx.x * ORD_WAVES + wv;
 	const int img = blockIdx.y;
+	if (!w.slow[img])
+		return;
 	const ImgInfo &I = w.info[img];
 	const unsigned T = I.T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
@@ -779,6 +789,121 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
 	}
 }
 
+// ----------------------------------------------------------- k_orders_fast ---
+// The common case needs no 32-state machinery.  The order map of a token is
+// monotone, so every start state ends between the chains started at 0 and at
+// 31; over 64 tokens those two almost always meet (orders decay by 2 per small
+// value), and then the group's exit order is a constant, whatever it was
+// entered with.  One lane per 64-token group: walk the 0- and the 31-chain; if
+// they met, the NEXT group's entry order is known, and a second walk records
+// each token's order and bit offset.  Lane 0 only serves as the predecessor of
+// lane 1 (63 groups of output per wave).  If any pair of chains did not meet
+// the image is flagged and the exact hierarchical pass (k_lut ... k_orders)
+// redoes it.  Tokens go through LDS in tiles of 16 per group, so that several
+// waves fit a SIMD.
+constexpr int FSUBS = 63;
+constexpr int QT = 16;
+
+struct FastTile {
+	unsigned run[64][QT + 1];
+	unsigned char flag[64][QT + 4];
+	unsigned char ord[64][QT + 4];
+	unsigned short off[64][QT + 2];
+};
+
+__global__ __launch_bounds__(256) void k_orders_fast(Work w)
+{
+	__shared__ FastTile tiles[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const long wave = (long)blockIdx.x * 4 + wv;
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const long T = I.T;
+	const long nsub = (T + SUB - 1) / SUB;
+	if (wave * FSUBS >= nsub)
+		return;
+	const unsigned *run = w.tok_run + img * w.TS;
+	const unsigned char *flag = w.tok_flag + img * w.TS;
+	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
+	FastTile &tile = tiles[wv];
+	const long S = wave * FSUBS - 1 + lane;          // this lane's 64-token group (lane 0: predecessor only)
+	const long tfirst = (wave * FSUBS - 1) * SUB;    // first token of the wave's window (-64 for wave 0)
+	const int lsub = lane >> 4, ltok = lane & 15;
+	auto load_tile = [&](int qt) {
+#pragma unroll 4
+		for (int k = 0; k < 16; ++k) {
+			const int sub = k * 4 + lsub;
+			const long t = tfirst + (long)sub * SUB + qt * QT + ltok;
+			const bool in = t >= 0 && t < T;
+			tile.run[sub][ltok] = in ? run[t] : 0u;
+			tile.flag[sub][ltok] = in ? flag[t] : (unsigned char)F_VOID;
+		}
+	};
+	int lo = 0, hi = 31;
+	for (int qt = 0; qt < SUB / QT; ++qt) {
+		load_tile(qt);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int t = 0; t < QT; ++t) {
+			const unsigned f = tile.flag[lane][t];
+			const unsigned v = tile.run[lane][t];
+			lo = vli_step(lo, v, f & F_VOID);
+			hi = vli_step(hi, v, f & F_VOID);
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	const bool valid = S >= 0 && S < nsub;
+	if (__ballot(valid && lo != hi)) {
+		if (lane == 0)
+			atomicOr(w.slow + img, 1);
+		return;   // the exact pass takes the whole image
+	}
+	int o = __shfl_up(lo, 1);          // the group before mine leaves in this order, whatever it entered with
+	if (S == 0)
+		o = I.order0;
+	const bool produces = lane >= 1 && valid;
+	const long t0 = S * SUB;
+	unsigned tokbits = 0;
+	unsigned long long rawbits = 0;
+	unsigned char *ord = w.tok_ord + img * w.TS;
+	unsigned short *off = w.tok_off + img * w.TS;
+	for (int qt = 0; qt < SUB / QT; ++qt) {
+		load_tile(qt);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int t = 0; t < QT; ++t) {
+			const unsigned f = tile.flag[lane][t];
+			tile.ord[lane][t] = (unsigned char)o;
+			tile.off[lane][t] = (unsigned short)tokbits;
+			if (!(f & F_VOID)) {
+				const int top = vli_top(o, tile.run[lane][t]);
+				tokbits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
+				o = vli_next(top);
+			}
+			if ((f & F_BREAK) && produces)
+				rawbits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + qt * QT + t))];
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+		for (int k = 0; k < 16; ++k) {
+			const int sub = k * 4 + lsub;
+			const long t = tfirst + (long)sub * SUB + qt * QT + ltok;
+			if (sub >= 1 && t < T) {
+				ord[t] = tile.ord[sub][ltok];
+				off[t] = tile.off[sub][ltok];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	unsigned long long total;
+	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
+	if (produces)
+		w.lane_bits[img * w.NCS * 64 + S] = pre;
+	if (lane == 0)
+		w.chunk_bits[img * w.NCS + wave] = total;
+}
+
 // ------------------------------------------------------------------ k_emit ---
 // bits.h:58-78: one lane per token.  The token's position is chunk base + its
 // lane-group's offset + its own offset (+ the refinement blocks of earlier break
@@ -801,7 +926,7 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 	const unsigned f = in ? w.tok_flag[img * w.TS + t] : F_VOID;
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	const long chunk = group >> 6;
+	const long chunk = group / (w.slow[img] ? 64 : FSUBS);
 	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[img * w.NCS * 64 + group] +
 		(in ? w.tok_off[img * w.TS + t] : 0);
 	// break tokens are followed by their segment's refinement block: later tokens of the group move up
@@ -872,7 +997,8 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 	__shared__ unsigned long long carry;
 	const int img = blockIdx.x;
 	ImgInfo &I = w.info[img];
-	const long nchunks = ((long)I.T + CHUNK - 1) / CHUNK;
+	const long nsub = ((long)I.T + SUB - 1) / SUB;
+	const long nchunks = w.slow[img] ? ((long)I.T + CHUNK - 1) / CHUNK : (nsub + FSUBS - 1) / FSUBS;
 	const unsigned long long *cb = w.chunk_bits + img * w.NCS;
 	unsigned long long *base = w.chunk_base + img * w.NCS;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1037,7 +1163,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	w.NT = NT;
 	w.ES = (long)NT * C * MAX_PLANES + 16;
 	w.TS = (long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8;
-	w.NCS = (w.TS + CHUNK - 1) / CHUNK;
+	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
 	w.NGS = (w.NCS + GROUP - 1) / GROUP;
 	const int nplanes = n * C;
 
@@ -1049,6 +1175,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 		const size_t o_planes = take(sizeof(int) * nplanes);
 		const size_t o_info = take(sizeof(ImgInfo) * n);
+		const size_t o_slow = take(sizeof(int) * n);
 		const size_t o_sd = take(sizeof(int) * (size_t)n * MAX_SEGS);
 		const size_t o_eb = take(sizeof(int) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
@@ -1060,6 +1187,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 			return DWTX_ERR_NOMEM;
 		w.planes_dev = (int *)(small + o_planes);
 		w.info = (ImgInfo *)(small + o_info);
+		w.slow = (int *)(small + o_slow);
 		w.seg_desc = (int *)(small + o_sd);
 		w.seg_ebase = (int *)(small + o_eb);
 		w.seg_refs = (unsigned *)(small + o_sr);
@@ -1067,6 +1195,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.brk_tok = (unsigned *)(small + o_bt);
 		w.segidx = (int *)(small + o_sx);
 		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
+		if (getenv("DWTX_FORCE_EXACT_ORDERS"))   // test hook: take the hierarchical 32-state pass for every image
+			DWTX_HIP(hipMemsetAsync(small + o_slow, 1, sizeof(int) * n, ctx->stream));
 
 		off = 0;
 		const size_t o_on = take(sizeof(short) * (size_t)n * w.ES);
@@ -1124,6 +1254,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_entries, dim3(n), dim3(1024), 0, s, g, w);
 	hipLaunchKernelGGL(k_tokens, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry, dim3(n), dim3(1024), 0, s, g, w);
+	hipLaunchKernelGGL(k_orders_fast, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
+	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
 	hipLaunchKernelGGL(k_lut, dim3((int)((w.NCS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
