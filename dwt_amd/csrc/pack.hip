@@ -587,13 +587,10 @@ __device__ __forceinline__ int vli_step(int o, unsigned v, bool skip)
 	return skip ? o : nx;
 }
 
-__global__ __launch_bounds__(256) void k_lut(Work w)
+__device__ __forceinline__ void lut_body(const Work &w, long vbx, int img)
 {
 	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
-	const long chunk = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
-	const int img = blockIdx.y;
-	if (!w.slow[img])
-		return;
+	const long chunk = (vbx * 4 + (threadIdx.x >> 6)) * 2 + half;
 	const unsigned T = w.info[img].T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
 	const long chunk_a = chunk - half;          // the wave's two chunks: a (lanes 0-31), a+1 (lanes 32-63)
@@ -631,14 +628,23 @@ __global__ __launch_bounds__(256) void k_lut(Work w)
 		w.lut[(img * w.NCS + chunk) * 32 + s] = (unsigned char)o;
 }
 
-// group maps: 32 lanes (states) walk the 64 chunk maps of a group
-__global__ __launch_bounds__(256) void k_chain_groups(Work w)
+// The exact pass only runs for images the fast pass flagged: a small fixed grid that
+// returns at once otherwise and strides over the virtual blocks when it has work.
+__global__ __launch_bounds__(256) void k_lut(Work w)
 {
-	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
-	const long group = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
 	const int img = blockIdx.y;
 	if (!w.slow[img])
 		return;
+	const long nvb = (w.NCS + 7) / 8;
+	for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x)
+		lut_body(w, vb, img);
+}
+
+// group maps: 32 lanes (states) walk the 64 chunk maps of a group
+__device__ __forceinline__ void chain_groups_body(const Work &w, long vbx, int img)
+{
+	const int lane = threadIdx.x & 63, half = lane >> 5, s = lane & 31;
+	const long group = (vbx * 4 + (threadIdx.x >> 6)) * 2 + half;
 	const unsigned T = w.info[img].T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
 	const long ngroups = (nchunks + GROUP - 1) / GROUP;
@@ -649,6 +655,16 @@ __global__ __launch_bounds__(256) void k_chain_groups(Work w)
 	for (long c = group * GROUP; c < min((group + 1) * GROUP, nchunks); ++c)
 		o = lut[c * 32 + o];
 	w.glut[(img * w.NGS + group) * 32 + s] = (unsigned char)o;
+}
+
+__global__ __launch_bounds__(256) void k_chain_groups(Work w)
+{
+	const int img = blockIdx.y;
+	if (!w.slow[img])
+		return;
+	const long nvb = (w.NGS + 7) / 8;
+	for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x)
+		chain_groups_body(w, vb, img);
 }
 
 // per image: serial over groups, then every group's chunks in parallel
@@ -726,14 +742,10 @@ struct OrdTile {
 	unsigned short off[64][66];
 };
 
-__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
+__device__ __forceinline__ void orders_body(const Work &w, OrdTile *tiles, long vbx, int img)
 {
-	__shared__ OrdTile tiles[ORD_WAVES];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const long chunk = (long)blockIdx.x * ORD_WAVES + wv;
-	const int img = blockIdx.y;
-	if (!w.slow[img])
-		return;
+	const long chunk = vbx * ORD_WAVES + wv;
 	const ImgInfo &I = w.info[img];
 	const unsigned T = I.T;
 	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
@@ -787,6 +799,18 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
 			off[t] = tile.off[r][lane];
 		}
 	}
+	__builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
+{
+	__shared__ OrdTile tiles[ORD_WAVES];
+	const int img = blockIdx.y;
+	if (!w.slow[img])
+		return;
+	const long nvb = (w.NCS + ORD_WAVES - 1) / ORD_WAVES;
+	for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x)
+		orders_body(w, tiles, vb, img);
 }
 
 // ----------------------------------------------------------- k_orders_fast ---
@@ -854,14 +878,43 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 		__builtin_amdgcn_wave_barrier();
 	}
 	const bool valid = S >= 0 && S < nsub;
-	if (__ballot(valid && lo != hi)) {
+	// A group whose two chains met leaves in a known order.  The rare other ones are resolved
+	// exactly as soon as their own entry order is known (one more walk, only in waves that have
+	// such a group); only if that chain of knowledge breaks (e.g. at the wave's predecessor lane)
+	// is the image handed to the exact pass.
+	int exitv = lo;
+	bool exit_known = lo == hi || !valid;
+	int o = 0;
+	bool entry_known = false;
+	for (int it = 0; it < 4; ++it) {
+		o = __shfl_up(exitv, 1);
+		entry_known = __shfl_up((int)exit_known, 1) != 0 && lane >= 1;
+		if (S == 0) {
+			o = I.order0;
+			entry_known = true;
+		}
+		const bool resolve = valid && !exit_known && entry_known;
+		if (!__ballot(resolve))
+			break;
+		int e = o;
+		for (int qt = 0; qt < SUB / QT; ++qt) {
+			load_tile(qt);
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int t = 0; t < QT; ++t)
+				e = vli_step(e, tile.run[lane][t], tile.flag[lane][t] & F_VOID);
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (resolve) {
+			exitv = e;
+			exit_known = true;
+		}
+	}
+	if (__ballot(lane >= 1 && valid && !entry_known)) {
 		if (lane == 0)
 			atomicOr(w.slow + img, 1);
 		return;   // the exact pass takes the whole image
 	}
-	int o = __shfl_up(lo, 1);          // the group before mine leaves in this order, whatever it entered with
-	if (S == 0)
-		o = I.order0;
 	const bool produces = lane >= 1 && valid;
 	const long t0 = S * SUB;
 	unsigned tokbits = 0;
@@ -1044,6 +1097,7 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 				I.total_bits = bytes * 8;
 		}
 		I.nbytes = bytes;
+		I.pad = w.slow[img];   // 1: the exact 32-state order pass had to run for this image
 	}
 }
 
@@ -1256,11 +1310,10 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_carry, dim3(n), dim3(1024), 0, s, g, w);
 	hipLaunchKernelGGL(k_orders_fast, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
 	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
-	hipLaunchKernelGGL(k_lut, dim3((int)((w.NCS + 7) / 8), n), dim3(256), 0, s, w);
-	hipLaunchKernelGGL(k_chain_groups, dim3((int)((w.NGS + 7) / 8), n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_lut, dim3(512, n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_chain_groups, dim3(64, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
-	const int cgrid = (int)((w.NCS + ORD_WAVES - 1) / ORD_WAVES);
-	hipLaunchKernelGGL(k_orders, dim3(cgrid, n), dim3(64 * ORD_WAVES), 0, s, w);
+	hipLaunchKernelGGL(k_orders, dim3(512, n), dim3(64 * ORD_WAVES), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
 	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.NCS * 64 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);

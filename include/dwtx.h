@@ -75,7 +75,7 @@ typedef struct dwtx_stream_info {
 	unsigned long long total_bits; /* encode.c:226: bit count before padding (8*capacity when truncated) */
 	unsigned long long nbytes;     /* bytes of the .dwt stream: min(capacity, ceil(total_bits/8)) */
 	int error;                     /* non-zero: unsupported data (more than 16 bit planes) */
-	int pad;
+	int exact_orders;              /* 1: the fast VLI-order pass did not resolve this image, the exact one ran */
 } dwtx_stream_info;
 
 /* Per-image result record of the decoder's entropy stage (host memory). */
