@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default per workload)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU reference (0 = skip)")
     ap.add_argument("--lift-reps", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: all ranks share cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -103,10 +105,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local)
     ctx = dwt_amd.Context(local)
 
