@@ -72,6 +72,11 @@ extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 	for (int i = 0; i < DWTX_SCRATCH_SLOTS; ++i)
 		if (c->scratch[i])
 			(void)hipFree(c->scratch[i]);
+	if (c->have_aux) {
+		(void)hipStreamDestroy(c->aux);
+		(void)hipEventDestroy(c->ev[0]);
+		(void)hipEventDestroy(c->ev[1]);
+	}
 	if (c->own_stream)
 		(void)hipStreamDestroy(c->stream);
 	free(c);

@@ -17,6 +17,9 @@ struct dwtx_ctx {
 	void *scratch[DWTX_SCRATCH_SLOTS];
 	size_t scratch_bytes[DWTX_SCRATCH_SLOTS];
 	dwtx_linplan *plans;   // per-geometry Hilbert block tables (linearize.hip)
+	hipStream_t aux;       // second stream: half of a decode batch runs here so that one half's serial
+	hipEvent_t ev[2];      // token walk overlaps the other half's parallel kernels (unpack.hip)
+	bool have_aux;
 };
 
 void dwtx_free_plans(dwtx_ctx *ctx);

@@ -1268,39 +1268,120 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	// the root image (written by the token walker when it has any bits) needs clearing
 	DWTX_HIP(hipMemset2DAsync(lin, sizeof(int) * (size_t)g.lin_stride, 0, sizeof(int) * (size_t)g.pixels[0], nplanes, s));
 	hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, nplanes);
-	{
-		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), n * FAM);
-		const size_t cnt_bytes = sizeof(unsigned) * (size_t)n * FAM * LINK_SHARDS;
-		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, s, w, streams, (long)stream_stride);
-		DWTX_HIP(hipMemsetAsync(w.todo_count[1], 0, cnt_bytes, s));
-		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, s, w, streams, (long)stream_stride);   // fills list 1
+
+	// everything below works on a range of images [i0, i0+cnt): all tables are per image
+	auto slice = [&](int i0) {
+		DWork h = w;
+		h.info += i0;
+		h.segidx += (size_t)i0 * 48 * MAX_PLANES;
+		h.seg_desc += (size_t)i0 * MAX_SEGS;
+		h.seg_symbase += (size_t)i0 * MAX_SEGS;
+		h.seg_b2 += (size_t)i0 * MAX_SEGS;
+		h.seg_n2done += (size_t)i0 * MAX_SEGS;
+		h.nonsig += (size_t)i0 * 48;
+		h.symbits += (size_t)i0 * w.BW;
+		h.tile_nonsig += (size_t)i0 * C * NT;
+		h.tile_rank += (size_t)i0 * C * MAX_PLANES * NT;
+		h.exitX += (size_t)i0 * FAM * w.NCH;
+		h.entryE += (size_t)i0 * FAM * w.NCH;
+		h.cs += (size_t)i0 * FAM * (w.NCH + 1);
+		h.ct += (size_t)i0 * FAM * (w.NCH + 1);
+		h.cg += (size_t)i0 * FAM * (w.NCH + 1);
+		h.part_s += (size_t)i0 * FAM * w.NB;
+		h.part_t += (size_t)i0 * FAM * w.NB;
+		h.part_g += (size_t)i0 * FAM * w.NB;
+		h.hop_seg += (size_t)i0 * w.MAX_HOPS;
+		h.hop_first += (size_t)i0 * w.MAX_HOPS;
+		h.hop_last += (size_t)i0 * w.MAX_HOPS;
+		h.hop_q0 += (size_t)i0 * w.MAX_HOPS;
+		h.hop_entry += (size_t)i0 * w.MAX_HOPS;
+		h.hop_ntok += (size_t)i0 * w.MAX_HOPS;
+		h.breaks += (size_t)i0 * FAM * w.NCH;
+		for (int k = 0; k < 2; ++k) {
+			h.todo[k] += (size_t)i0 * FAM * 64 * w.todo_cap;
+			h.todo_count[k] += (size_t)i0 * FAM * 64;
+		}
+		h.nhops += i0;
+		if (h.dbg)
+			h.dbg += (size_t)i0 * 4;
+		return h;
+	};
+	// chunk tables; then (walk) token walk and symbol bits of the hopped-over chunks
+	auto pre = [&](hipStream_t st, int i0, int cnt) -> int {
+		const DWork h = slice(i0);
+		const unsigned char *str = streams + (size_t)i0 * stream_stride;
+		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), cnt * FAM);
+		const size_t cnt_bytes = sizeof(unsigned) * (size_t)cnt * FAM * LINK_SHARDS;
+		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
+		DWTX_HIP(hipMemsetAsync(h.todo_count[1], 0, cnt_bytes, st));
+		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // fills list 1
 		int cur = 1;
 		for (int r = 2; r <= LINK_ROUNDS; ++r) {
-			DWTX_HIP(hipMemsetAsync(w.todo_count[cur ^ 1], 0, cnt_bytes, s));
-			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, n * FAM), dim3(256), 0, s, w, streams, (long)stream_stride, cur);
+			DWTX_HIP(hipMemsetAsync(h.todo_count[cur ^ 1], 0, cnt_bytes, st));
+			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur);
 			cur ^= 1;
 		}
-		hipLaunchKernelGGL(k_link_final, cg, dim3(256), 0, s, w);
-		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
-		hipLaunchKernelGGL(k_scan_parts, dim3(n * FAM), dim3(256), 0, s, w);
-		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, n * FAM), dim3(256), 0, s, w);
-		hipLaunchKernelGGL(k_breaks, dim3((unsigned)((w.NCH + 255) / 256), n * FAM), dim3(256), 0, s, w);
-	}
-	hipLaunchKernelGGL(k_tokenize, dim3(n), dim3(64), 0, s, g, w, streams, (long)stream_stride, dev_lens, lin, n);
-	hipLaunchKernelGGL(k_hopbits, dim3((unsigned)((w.NCH + 255) / 256), n), dim3(256), 0, s, w, streams, (long)stream_stride);
-	DWTX_LAUNCH_CHECK();
+		hipLaunchKernelGGL(k_link_final, cg, dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_parts, dim3(cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_breaks, dim3((unsigned)((w.NCH + 255) / 256), cnt * FAM), dim3(256), 0, st, h);
+		DWTX_LAUNCH_CHECK();
+		return DWTX_OK;
+	};
+	auto walk = [&](hipStream_t st, int i0, int cnt) -> int {
+		const DWork h = slice(i0);
+		const unsigned char *str = streams + (size_t)i0 * stream_stride;
+		hipLaunchKernelGGL(k_tokenize, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
+			lin + (size_t)i0 * C * g.lin_stride, cnt);
+		hipLaunchKernelGGL(k_hopbits, dim3((unsigned)((w.NCH + 255) / 256), cnt), dim3(256), 0, st, h, str, (long)stream_stride);
+		DWTX_LAUNCH_CHECK();
+		return DWTX_OK;
+	};
 	static_assert(sizeof(dwtx_decode_info) == sizeof(DecInfo), "DecInfo is the device image of dwtx_decode_info");
-	DWTX_HIP(hipMemcpyAsync(host_info, w.info, sizeof(DecInfo) * (size_t)n, hipMemcpyDeviceToHost, s));
-	DWTX_HIP(hipStreamSynchronize(s));
-	int pmax = 0;
-	for (int i = 0; i < n; ++i)
-		if (!host_info[i].status && host_info[i].pmax > pmax)
-			pmax = host_info[i].pmax;
-	for (int p = pmax - 1; p >= 0; --p) {
-		hipLaunchKernelGGL(k_rank, dim3(g.levels, nplanes), dim3(1024), 0, s, g, w, p);
-		hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, p);
+	// walker results to the host (synchronises the stream), then the plane scatter
+	auto post = [&](hipStream_t st, int i0, int cnt) -> int {
+		const DWork h = slice(i0);
+		DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+		DWTX_HIP(hipStreamSynchronize(st));
+		int pmax = 0;
+		for (int i = i0; i < i0 + cnt; ++i)
+			if (!host_info[i].status && host_info[i].pmax > pmax)
+				pmax = host_info[i].pmax;
+		for (int p = pmax - 1; p >= 0; --p) {
+			hipLaunchKernelGGL(k_rank, dim3(g.levels, cnt * C), dim3(1024), 0, st, g, h, p);
+			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT, 256), cnt * C), dim3(256), 0, st, g, h, p);
+		}
+		hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), cnt * C), dim3(256), 0, st, g, h,
+			streams + (size_t)i0 * stream_stride, (long)stream_stride, lin + (size_t)i0 * C * g.lin_stride);
+		DWTX_LAUNCH_CHECK();
+		return DWTX_OK;
+	};
+	int rc;
+	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
+		if ((rc = pre(s, 0, n)) || (rc = walk(s, 0, n)) || (rc = post(s, 0, n)))
+			return rc;
+		return DWTX_OK;
 	}
-	hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, w, streams, (long)stream_stride, lin);
-	DWTX_LAUNCH_CHECK();
+	// The token walk is one wave per image and leaves the chip idle: run the two halves of the batch
+	// on two streams, the second one half a pipeline behind, so that each half's walk overlaps the
+	// other half's parallel kernels.
+	if (!ctx->have_aux) {
+		DWTX_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+		DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[0], hipEventDisableTiming));
+		DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[1], hipEventDisableTiming));
+		ctx->have_aux = true;
+	}
+	const int na = n / 2;
+	if ((rc = pre(s, 0, na)))
+		return rc;
+	DWTX_HIP(hipEventRecord(ctx->ev[0], s));              // first half's tables done: its walk starts now
+	DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
+	if ((rc = walk(s, 0, na)) || (rc = pre(ctx->aux, na, n - na)) || (rc = walk(ctx->aux, na, n - na)))
+		return rc;
+	if ((rc = post(s, 0, na)) || (rc = post(ctx->aux, na, n - na)))
+		return rc;
+	DWTX_HIP(hipEventRecord(ctx->ev[1], ctx->aux));
+	DWTX_HIP(hipStreamWaitEvent(s, ctx->ev[1], 0));
 	return DWTX_OK;
 }
