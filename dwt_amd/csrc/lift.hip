@@ -19,6 +19,8 @@
 //   odd-length line: the last even sample is NOT updated (not symmetric!)
 #include "dwtx_internal.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int WAVES = 4;          // waves per block, stacked along y
@@ -324,16 +326,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 		const FwdRaw r0 = fwd_load_w(src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid);
 		fwd_lift_w(r0, q, lane, A.nquads, l0, h0);
 	}
-	// rows 2jj+1 and 2jj+2 of the coming iteration, loaded one iteration ahead
-	FwdRaw n1 = fwd_load_w(src + (long)min(2 * jj + 1, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
-	FwdRaw n2 = fwd_load_w(src + (long)min(2 * jj + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+	// rows 2jj+1, 2jj+2 of the next two iterations are kept in flight: one wave alone cannot cover
+	// the HBM latency with a single row pair outstanding
+	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
+	FwdRaw n1 = fwd_load_w(rowp(2 * jj + 1), q, lane, A.nquads, valid);
+	FwdRaw n2 = fwd_load_w(rowp(2 * jj + 2), q, lane, A.nquads, valid);
+	FwdRaw m1 = fwd_load_w(rowp(2 * jj + 3), q, lane, A.nquads, valid);
+	FwdRaw m2 = fwd_load_w(rowp(2 * jj + 4), q, lane, A.nquads, valid);
 	for (; jj < j1; ++jj) {
 		const int r1 = 2 * jj + 1, r2 = r1 + 1;
 		const bool odd_in = r1 < a.h;
 		const FwdRaw c1 = n1, c2 = n2;
-		if (jj + 1 < j1) {
-			n1 = fwd_load_w(src + (long)min(r1 + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
-			n2 = fwd_load_w(src + (long)min(r2 + 2, a.h - 1) * a.spitch, q, lane, A.nquads, valid);
+		n1 = m1;
+		n2 = m2;
+		if (jj + 2 < j1) {
+			m1 = fwd_load_w(rowp(r1 + 4), q, lane, A.nquads, valid);
+			m2 = fwd_load_w(rowp(r2 + 4), q, lane, A.nquads, valid);
 		}
 		I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
 		if (odd_in)
@@ -435,15 +443,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 		pdl = to_i2(p.dl);
 		pdh = to_i2(p.dh);
 	}
+	// the subband rows of the next two row pairs are kept in flight (see k_fwd_level_w)
 	InvRaw cur = inv_load_w(a, llp, det, j0, qd, valid);
 	InvRaw nxt = inv_load_w(a, llp, det, j0 + 1, qd, valid);
+	InvRaw nx2 = inv_load_w(a, llp, det, j0 + 2, qd, valid);
 	I2 dl = to_i2(cur.dl), dh = to_i2(cur.dh);
 	I2 el = even_of(j0, to_i2(cur.sl), pdl, dl), eh = even_of(j0, to_i2(cur.sh), pdh, dh);
 	for (int jj = j0; jj < j1; ++jj) {
 		const int r0 = 2 * jj, r1 = r0 + 1;
 		const InvRaw n = nxt;
-		if (jj + 1 < j1)
-			nxt = inv_load_w(a, llp, det, jj + 2, qd, valid);
+		nxt = nx2;
+		if (jj + 2 < j1)
+			nx2 = inv_load_w(a, llp, det, jj + 3, qd, valid);
 		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el, neh = eh;   // mirror x[h] := x[h-2]
 		if (r1 + 1 < a.h) {
 			ndl = to_i2(n.dl);
@@ -780,12 +791,28 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 			tail_from = t;
 			break;
 		}
-	for (int t = 0; t < T; ++t) {
+	// the LL band ping-pongs between the two scratch planes (tmp[0] holds up to ws[1]*hs[1], tmp[1]
+	// up to ws[2]*hs[2]); the last level writes it into the pyramid itself
+	const int *src = in;
+	long src_ps = full_ps;
+	int spitch = W;
+	auto ll_dest = [&](int k, int *&p, long &ps, int &pitch) {   // destination of the ws[k]*hs[k] LL band
+		if (k == T) {
+			p = out;
+			ps = full_ps;
+			pitch = W;
+			return;
+		}
+		p = src == tmp[0] ? tmp[1] : tmp[0];   // never the plane being read; from tmp[0] only bands <= ws[2]*hs[2] follow
+		ps = (long)ws[k] * hs[k];
+		pitch = ws[k];
+	};
+	for (int t = 0; t < T;) {
 		if (t == tail_from) {
 			TailArgs ta;
-			ta.src = t == 0 ? in : tmp[(t - 1) & 1];
-			ta.src_ps = t == 0 ? full_ps : (long)ws[t] * hs[t];
-			ta.spitch = t == 0 ? W : ws[t];
+			ta.src = src;
+			ta.src_ps = src_ps;
+			ta.spitch = spitch;
 			ta.dst = nullptr;
 			ta.dst_ps = 0;
 			ta.dpitch2 = 0;
@@ -806,24 +833,10 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 		a.h = hs[t];
 		a.w2 = ws[t + 1];
 		a.h2 = hs[t + 1];
-		if (t == 0) {
-			a.src = in;
-			a.src_ps = full_ps;
-			a.spitch = W;
-		} else {
-			a.src = tmp[(t - 1) & 1];
-			a.src_ps = (long)ws[t] * hs[t];
-			a.spitch = ws[t];
-		}
-		if (t == T - 1) {
-			a.ll = out;
-			a.ll_ps = full_ps;
-			a.llpitch = W;
-		} else {
-			a.ll = tmp[t & 1];
-			a.ll_ps = (long)a.w2 * a.h2;
-			a.llpitch = a.w2;
-		}
+		a.src = src;
+		a.src_ps = src_ps;
+		a.spitch = spitch;
+		ll_dest(t + 1, a.ll, a.ll_ps, a.llpitch);
 		a.det = out;
 		a.det_ps = full_ps;
 		a.dpitch = W;
@@ -845,6 +858,10 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 			hipLaunchKernelGGL(k_fwd_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
 		}
 		DWTX_LAUNCH_CHECK();
+		src = a.ll;
+		src_ps = a.ll_ps;
+		spitch = a.llpitch;
+		++t;
 	}
 	return DWTX_OK;
 }
