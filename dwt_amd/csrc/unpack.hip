@@ -259,6 +259,45 @@ __device__ __forceinline__ bool token_at(unsigned long long win, int o, int &len
 	return true;
 }
 
+// Walk the tokens of one chunk from (off, o) until off leaves the chunk.  visit(run, neg) is called
+// for every token before it is consumed and may return false to stop there (off/o then still
+// describe that token).  Returns false if some position cannot hold a token (dead path).
+// The chunk is cut into four 32-bit segments with compile-time register indices; almost every
+// token fits the 32-bit window of its segment (v_alignbit), the rare long one takes the 64-bit path.
+template <class F>
+__device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, F &&visit)
+{
+	const unsigned d[6] = { (unsigned)c.w0, (unsigned)(c.w0 >> 32), (unsigned)c.w1, (unsigned)(c.w1 >> 32),
+		(unsigned)c.w2, (unsigned)(c.w2 >> 32) };
+#pragma unroll
+	for (int seg = 0; seg < CH_BITS / 32; ++seg) {
+		while (off < 32 * (seg + 1)) {
+			const int r = off - 32 * seg;
+			const unsigned w32 = __builtin_amdgcn_alignbit(d[seg + 1], d[seg], r);
+			int len, next;
+			unsigned run, neg;
+			const int z = w32 ? __builtin_ctz(w32) : 32;
+			const int top = o + z;
+			if (z + top + 2 <= 32) {
+				len = z + top + 2;
+				run = ((w32 >> (z + 1)) & ((1u << top) - 1u)) + (1u << top) - (1u << o);
+				neg = (w32 >> (z + 1 + top)) & 1u;
+				next = top >= 2 ? top - 2 : 0;
+			} else {
+				const unsigned long long lo64 = d[seg] | ((unsigned long long)d[seg + 1] << 32);
+				const unsigned long long w64 = r ? (lo64 >> r) | ((unsigned long long)d[seg + 2] << (64 - r)) : lo64;
+				if (!token_at(w64, o, len, run, neg, next))
+					return false;
+			}
+			if (!visit(run, neg))
+				return true;
+			off += len;
+			o = next;
+		}
+	}
+	return true;
+}
+
 __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,19 +308,8 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 	// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
 	// number of bits apart cannot meet while the order stays 0: seed both parities.
 	int off = vs % FAM, o = 0;
-	unsigned short out = 0xffff;
-	for (;;) {
-		int len, next;
-		unsigned run, neg;
-		if (!token_at(chunk_win(c, off), o, len, run, neg, next))
-			break;
-		off += len;
-		o = next;
-		if (off >= CH_BITS) {
-			out = (unsigned short)((off - CH_BITS) | (o << 8));
-			break;
-		}
-	}
+	const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
+	const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
 	w.exitX[vs * w.NCH + chunk] = out;
 }
 
@@ -308,20 +336,12 @@ __device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *
 	if (in != 0xffff) {
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
 		int off = in & 0xff, o = in >> 8;
-		bool dead = false;
-		while (off < CH_BITS) {
-			int len, next;
-			unsigned run, neg;
-			if (!token_at(chunk_win(c, off), o, len, run, neg, next)) {
-				dead = true;
-				break;
-			}
-			off += len;
-			o = next;
+		const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
 			++tok;
 			sym += (unsigned long long)run + 1ull;
-		}
-		if (!dead)
+			return true;
+		});
+		if (alive)
 			out = (unsigned short)((off - CH_BITS) | (o << 8));
 	}
 	const unsigned short old = w.exitX[vs * w.NCH + ch];
@@ -589,13 +609,9 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		// symbol positions only grow: gather the bits of one bitmap word before touching memory
 		long cur = -1;
 		unsigned acc = 0;
-		while (off < CH_BITS && left) {
-			int len, next;
-			unsigned run, neg;
-			if (!token_at(chunk_win(c, off), o, len, run, neg, next))
-				break;
-			off += len;
-			o = next;
+		chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
+			if (!left)
+				return false;
 			pos += run;
 			const long wi = (long)(pos >> 4);
 			if (wi != cur) {
@@ -607,7 +623,8 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			acc |= (1u | (neg << 1)) << ((pos & 15) * 2);
 			++pos;
 			--left;
-		}
+			return true;
+		});
 		if (acc)
 			atomicOr(sym + cur, acc);
 	}
@@ -798,18 +815,13 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 						int off = rel, o = order;
 						unsigned tok = 0;
 						unsigned long long sym = 0;
-						while (off < CH_BITS) {
-							int len, next;
-							unsigned run, neg;
-							if (!token_at(chunk_win(cw, off), o, len, run, neg, next))
-								break;
+						chunk_walk(cw, off, o, [&](unsigned run, unsigned) {
 							if (sym + run + 1 > (unsigned long long)need)
-								break;   // this token's run reaches past the segment: the careful path below takes it
+								return false;   // this token's run reaches past the segment: the careful path below takes it
 							sym += (unsigned long long)run + 1;
 							++tok;
-							off += len;
-							o = next;
-						}
+							return true;
+						});
 						if (tok) {
 							hop_seg[nhops] = k;
 							hop_first[nhops] = (unsigned)ci;
