@@ -191,9 +191,10 @@ struct BitmapWriter {
 	unsigned *sym;
 	long cur;
 	unsigned acc;
+	bool lead;   // the walker runs with all lanes of its wave in step: only one of them may add to memory
 	__device__ __forceinline__ void flush()
 	{
-		if (cur >= 0 && acc)   // hop chunks add their bits to the same words later (k_hopbits)
+		if (cur >= 0 && acc && lead)   // hop chunks add their bits to the same words later (k_hopbits)
 			atomicOr(sym + cur, acc);
 		acc = 0;
 	}
@@ -296,6 +297,46 @@ __device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, 
 		}
 	}
 	return true;
+}
+
+// The walker's own parse of the rest of one chunk: counts tokens and symbols from (off, o) until the
+// chunk ends, the next token's run would pass `need` symbols, or a token does not fit a 32-bit
+// window (the careful path takes that one).  All 64 lanes of the wave must be active and every
+// argument uniform: lane i holds the 32 stream bits from chunk offsets i and 64+i, so the serial
+// token chain fetches its window with one v_readlane and otherwise runs on the scalar unit.
+struct ChunkScan {
+	unsigned tok, sym;
+	int off, o;
+};
+
+__device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int o, unsigned need)
+{
+	const int lane = (int)threadIdx.x & 63;
+	const unsigned d0 = (unsigned)c.w0, d1 = (unsigned)(c.w0 >> 32), d2 = (unsigned)c.w1, d3 = (unsigned)(c.w1 >> 32),
+		d4 = (unsigned)c.w2;
+	const bool up = lane >= 32;
+	const unsigned winA = __builtin_amdgcn_alignbit(up ? d2 : d1, up ? d1 : d0, (unsigned)lane & 31u);
+	const unsigned winB = __builtin_amdgcn_alignbit(up ? d4 : d3, up ? d3 : d2, (unsigned)lane & 31u);
+	unsigned tok = 0, left = need;   // left = symbols the segment still takes
+	// branch-free token step (single-exit loops keep the scalar code tight); false = stop at this token
+	auto token = [&](unsigned w32) -> bool {
+		const int z = w32 ? __builtin_ctz(w32) : 32;
+		const int top = o + z;
+		const unsigned run = ((w32 >> ((z + 1) & 31)) & ((1u << (top & 31)) - 1u)) + (1u << (top & 31)) - (1u << o);
+		const bool ok = z + top <= 30 && run < left;   // fits the window, and the run stays inside the segment
+		left -= ok ? run + 1u : 0u;
+		tok += ok ? 1u : 0u;
+		off += ok ? z + top + 2 : 0;
+		o = ok ? max(top, 2) - 2 : o;
+		return ok;
+	};
+	bool ok = true;
+	while (ok && off < 64)
+		ok = token((unsigned)__builtin_amdgcn_readlane((int)winA, off));
+	while (ok && off < 128)
+		ok = token((unsigned)__builtin_amdgcn_readlane((int)winB, off - 64));
+	ChunkScan r = { tok, need - left, off, o };
+	return r;
 }
 
 __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
@@ -636,8 +677,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	const unsigned long long *lens, int *lin, int n)
 {
 	const int img = blockIdx.x;
-	if (img >= n || threadIdx.x)
+	if (img >= n)
 		return;
+	// All 64 lanes walk in step on uniform values (the compiler keeps them on the scalar unit), so that
+	// chunk_scan can use the lanes; plain stores just repeat the same value, atomics are lane 0's.
 	DecInfo &I = w.info[img];
 	I.status = 1;
 	I.W = g.W;
@@ -708,6 +751,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	bm.sym = w.symbits + img * w.BW;
 	bm.cur = -1;
 	bm.acc = 0;
+	bm.lead = threadIdx.x == 0;
 
 	unsigned cnt = 0;              // rle.h:25
 	unsigned long long symtotal = 0;
@@ -721,7 +765,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	const unsigned long long *s64 = (const unsigned long long *)s8;
 	// chunk i is safe to parse blindly if every token starting in it ends inside the data
 	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
-	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter();
+	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter(), n_fast = 0;
 	long checked = -1;
 	int nhops = 0;
 	unsigned hopped = 0, walked = 0;
@@ -811,17 +855,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					t_hop += tq1 - tq0;
 					if (!moved) {
 						// parse the rest of this chunk ourselves, counting only; k_hopbits sets the bits later
-						const ChunkWin cw = chunk_load(s64, br.n64, ci);
-						int off = rel, o = order;
-						unsigned tok = 0;
-						unsigned long long sym = 0;
-						chunk_walk(cw, off, o, [&](unsigned run, unsigned) {
-							if (sym + run + 1 > (unsigned long long)need)
-								return false;   // this token's run reaches past the segment: the careful path below takes it
-							sym += (unsigned long long)run + 1;
-							++tok;
-							return true;
-						});
+						++n_fast;
+						const ChunkScan cs = chunk_scan(chunk_load(s64, br.n64, ci), rel, order, need);
+						const unsigned tok = cs.tok, sym = cs.sym;
+						const int off = cs.off, o = cs.o;
 						if (tok) {
 							hop_seg[nhops] = k;
 							hop_first[nhops] = (unsigned)ci;
@@ -953,7 +990,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.hopped_chunks = hopped;
 	I.walked_tokens = walked;
 	I.pad = 0;
-	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; }
+	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; w.dbg[img * 4 + 3] = n_fast; }
 	I.level = level;
 	I.nsegs = nsegs;
 	I.truncated = stop ? 1 : 0;

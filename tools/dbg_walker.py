@@ -14,4 +14,4 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.cpu().tolist()
 i = infos[0]
-print(f"walker cycles total {d[0]} (~{d[0]/100e6*1e3:.2f} ms at 100MHz refclk?)  hop-check {d[1]}  fast-parse {d[2]}  hops={i.hops} walked={i.walked_tokens}")
+print(f"walker cycles total {d[0]} (~{d[0]/100e6*1e3:.2f} ms at 100MHz refclk?)  hop-check {d[1]}  fast-parse {d[2]}  hops={i.hops} walked={i.walked_tokens} nfast={d[3]}")
