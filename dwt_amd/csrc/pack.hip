@@ -22,7 +22,7 @@
 //   k_tokens  one wave per entry: classify 64 coefficients per row at the
 //             entry's plane; every significant one becomes a token
 //             (zero run since the previous one in this tile, sign).
-//   k_carry   per image: segmented scan of pending zero runs across entries,
+//   k_carry_* batch-wide segmented scan of pending zero runs across entries,
 //             segment ends (phantom terminators, rle.h:79-89) and the final
 //             flush; patches the first token of each entry.
 //   k_lut/k_chain*/k_orders  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0)
@@ -72,6 +72,11 @@ struct ImgInfo {
 	int pad;
 };
 
+// pending-run map of the carry scan (k_carry_*): s -> add + (keep ? s : 0)
+struct RunMap {
+	unsigned keep, add;
+};
+
 struct Work {
 	// per plane
 	unsigned short *cum;        // [nplanes][NT][32]
@@ -102,8 +107,10 @@ struct Work {
 	unsigned long long *chunk_bits;    // [n][NCS]
 	unsigned long long *chunk_base;    // [n][NCS]
 	unsigned long long *lane_bits;     // [n][NCS*64] per 64-token group: bit offset inside its wave's chunk
+	RunMap *carry_agg;                 // [n][NCB] map of each block of 1024 entries
+	unsigned *carry_in;                // [n][NCB] pending run entering the block
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
-	long ES, TS, NCS, NGS;
+	long ES, TS, NCS, NGS, NCB;
 	int NT;
 };
 
@@ -498,10 +505,6 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 // and resets it (rle.h:79-89); without refinement bits the run carries on.
 // Maps are (keep, add): s -> add + (keep ? s : 0).
 
-struct RunMap {
-	unsigned keep, add;
-};
-
 __device__ __forceinline__ RunMap compose(RunMap a, RunMap b)   // a then b
 {
 	RunMap r;
@@ -510,68 +513,141 @@ __device__ __forceinline__ RunMap compose(RunMap a, RunMap b)   // a then b
 	return r;
 }
 
-__global__ __launch_bounds__(1024) void k_carry(PackGeom g, Work w)
+// The scan runs over all entries of a batch at once: k_carry_local reduces blocks of 1024
+// entries to one map each, k_carry_blocks scans those per image (and writes the final flush
+// token), k_carry_apply redoes the block-local scan from the block's entry state and patches
+// the tokens.
+
+constexpr int CARRY_BLOCK = 1024;
+
+__device__ __forceinline__ RunMap carry_map_of(const Work &w, const ImgInfo &I, int img, int e, bool &has_one, bool &seg_end, bool &refs)
 {
-	__shared__ RunMap sm[1024];
-	const int img = blockIdx.x;
-	ImgInfo &I = w.info[img];
-	const int K = I.K, E = I.E;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const unsigned short *ones = w.ent_ones + img * w.ES, *tz = w.ent_tz + img * w.ES;
-	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1);
-	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
-	unsigned *tok_run = w.tok_run + img * w.TS;
-	unsigned char *tok_flag = w.tok_flag + img * w.TS;
-	const int per = (E + 1023) / 1024;
-	const int e0 = threadIdx.x * per, e1 = min(e0 + per, E);
+	RunMap t = { 1u, 0u };
+	has_one = seg_end = refs = false;
+	if (e < I.E) {
+		const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+		has_one = w.ent_ones[img * w.ES + e] != 0;
+		t.keep = has_one ? 0u : 1u;
+		t.add = w.ent_tz[img * w.ES + e];
+		const int k = seg_of_entry(eb, I.K, e);
+		seg_end = e == eb[k + 1] - 1;
+		refs = seg_end && w.seg_refs[(long)img * MAX_SEGS + k] != 0;
+	}
+	return t;
+}
 
-	auto walk = [&](unsigned s, bool apply) {
-		RunMap m = { 1u, 0u };
-		int k = e0 < e1 ? seg_of_entry(eb, K, e0) : 0;
-		for (int e = e0; e < e1; ++e) {
-			while (e >= eb[k + 1])
-				++k;
-			const bool has_one = ones[e] != 0;
-			if (apply && has_one)
-				tok_run[tokbase[e]] += s;
-			RunMap t = { has_one ? 0u : 1u, tz[e] };
-			s = t.add + (t.keep ? s : 0u);
-			m = compose(m, t);
-			if (e == eb[k + 1] - 1) {   // segment end: the break slot
-				const bool refs = srefs[k] != 0;
-				if (apply) {
-					const unsigned idx = tokbase[e] + ones[e];
-					tok_run[idx] = s;
-					tok_flag[idx] = (unsigned char)(F_BREAK | ((refs && s) ? 0u : F_VOID));
-				}
-				if (refs) {
-					RunMap z = { 0u, 0u };
-					m = compose(m, z);
-					s = 0;
-				}
-			}
-		}
-		return apply ? RunMap{ 0u, s } : m;
-	};
-
-	RunMap mine = walk(0, false);
-	sm[threadIdx.x] = mine;
+// inclusive scan of one map per thread over a block of 1024; wagg = 16 maps of LDS
+__device__ __forceinline__ RunMap block_scan_maps(RunMap m, RunMap *wagg, RunMap &total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int o = 1; o < 64; o <<= 1) {
+		RunMap a;
+		a.keep = __shfl_up(m.keep, o);
+		a.add = __shfl_up(m.add, o);
+		if (lane >= o)
+			m = compose(a, m);
+	}
+	if (lane == 63)
+		wagg[wv] = m;
 	__syncthreads();
-	for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan of maps
-		RunMap a = sm[threadIdx.x];
-		RunMap b = a;
-		if ((int)threadIdx.x >= o)
-			b = compose(sm[threadIdx.x - o], a);
+	RunMap pre = { 1u, 0u }, all = { 1u, 0u };
+	for (int k = 0; k < 16; ++k) {
+		const RunMap a = wagg[k];
+		if (k < wv)
+			pre = compose(pre, a);
+		all = compose(all, a);
+	}
+	__syncthreads();
+	total = all;
+	return compose(pre, m);
+}
+
+__global__ __launch_bounds__(CARRY_BLOCK) void k_carry_local(Work w)
+{
+	__shared__ RunMap wagg[16];
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	if ((int)blockIdx.x * CARRY_BLOCK >= I.E)
+		return;
+	const int e = blockIdx.x * CARRY_BLOCK + threadIdx.x;
+	bool has_one, seg_end, refs;
+	RunMap t = carry_map_of(w, I, img, e, has_one, seg_end, refs);
+	if (refs)
+		t = RunMap{ 0u, 0u };   // the break slot takes the pending run, the next segment starts from 0
+	RunMap total;
+	block_scan_maps(t, wagg, total);
+	if (threadIdx.x == 0)
+		w.carry_agg[img * w.NCB + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CARRY_BLOCK) void k_carry_blocks(Work w)
+{
+	__shared__ RunMap wagg[16];
+	const int img = blockIdx.x;
+	const ImgInfo &I = w.info[img];
+	const int nb = (I.E + CARRY_BLOCK - 1) / CARRY_BLOCK;
+	unsigned s = 0;   // state 0 at stream start (rle.h:33)
+	for (int b0 = 0; b0 < nb; b0 += CARRY_BLOCK) {
+		const int b = b0 + threadIdx.x;
+		const RunMap mine = b < nb ? w.carry_agg[img * w.NCB + b] : RunMap{ 1u, 0u };
+		RunMap total;
+		const RunMap inc = block_scan_maps(mine, wagg, total);
+		// state entering block b = everything before it applied to s: inclusive minus own = shift by one
+		RunMap ex;
+		ex.keep = __shfl_up(inc.keep, 1);
+		ex.add = __shfl_up(inc.add, 1);
+		__shared__ RunMap edge[16];
+		if ((threadIdx.x & 63) == 63)
+			edge[threadIdx.x >> 6] = inc;
 		__syncthreads();
-		sm[threadIdx.x] = b;
+		if ((threadIdx.x & 63) == 0)
+			ex = threadIdx.x ? edge[(threadIdx.x >> 6) - 1] : RunMap{ 1u, 0u };
+		if (b < nb)
+			w.carry_in[img * w.NCB + b] = ex.add + (ex.keep ? s : 0u);
+		s = total.add + (total.keep ? s : 0u);
 		__syncthreads();
 	}
-	const unsigned s_in = threadIdx.x ? sm[threadIdx.x - 1].add : 0u;   // state 0 at stream start (rle.h:33)
-	walk(s_in, true);
-	if (threadIdx.x == 1023) {
-		const unsigned s_end = sm[1023].add;
-		tok_run[I.T - 1] = s_end;                 // encode.c:221 rle_flush: always emitted
-		tok_flag[I.T - 1] = (unsigned char)F_FLUSH;
+	if (threadIdx.x == 0) {
+		w.tok_run[img * w.TS + I.T - 1] = s;                 // encode.c:221 rle_flush: always emitted
+		w.tok_flag[img * w.TS + I.T - 1] = (unsigned char)F_FLUSH;
+	}
+}
+
+__global__ __launch_bounds__(CARRY_BLOCK) void k_carry_apply(Work w)
+{
+	__shared__ RunMap wagg[16];
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	if ((int)blockIdx.x * CARRY_BLOCK >= I.E)
+		return;
+	const int e = blockIdx.x * CARRY_BLOCK + threadIdx.x;
+	bool has_one, seg_end, refs;
+	const RunMap own = carry_map_of(w, I, img, e, has_one, seg_end, refs);
+	const RunMap t = refs ? RunMap{ 0u, 0u } : own;
+	RunMap total;
+	const RunMap inc = block_scan_maps(t, wagg, total);
+	RunMap ex;
+	ex.keep = __shfl_up(inc.keep, 1);
+	ex.add = __shfl_up(inc.add, 1);
+	__shared__ RunMap edge[16];
+	if ((threadIdx.x & 63) == 63)
+		edge[threadIdx.x >> 6] = inc;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0)
+		ex = threadIdx.x ? edge[(threadIdx.x >> 6) - 1] : RunMap{ 1u, 0u };
+	if (e >= I.E)
+		return;
+	const unsigned s_blk = w.carry_in[img * w.NCB + blockIdx.x];
+	const unsigned s_in = ex.add + (ex.keep ? s_blk : 0u);
+	unsigned *tok_run = w.tok_run + img * w.TS;
+	const unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
+	if (has_one)
+		tok_run[tb] += s_in;
+	if (seg_end) {   // the break slot
+		const unsigned s = own.add + (own.keep ? s_in : 0u);
+		const unsigned idx = tb + w.ent_ones[img * w.ES + e];
+		tok_run[idx] = s;
+		w.tok_flag[img * w.TS + idx] = (unsigned char)(F_BREAK | ((refs && s) ? 0u : F_VOID));
 	}
 }
 
@@ -1219,6 +1295,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	w.TS = (long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8;
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
 	w.NGS = (w.NCS + GROUP - 1) / GROUP;
+	w.NCB = (w.ES + CARRY_BLOCK - 1) / CARRY_BLOCK;
 	const int nplanes = n * C;
 
 	// carve scratch
@@ -1259,6 +1336,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_tz = take(sizeof(short) * (size_t)n * w.ES);
 		const size_t o_tb = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_rc = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
+		const size_t o_ca = take(sizeof(RunMap) * (size_t)n * w.NCB);
+		const size_t o_ci = take(sizeof(unsigned) * (size_t)n * w.NCB);
 		char *ent = (char *)dwtx_scratch(ctx, SLOT_PK_ENT, off);
 		if (!ent)
 			return DWTX_ERR_NOMEM;
@@ -1268,6 +1347,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.ent_tz = (unsigned short *)(ent + o_tz);
 		w.ent_tokbase = (unsigned *)(ent + o_tb);
 		w.ent_refscum = (unsigned *)(ent + o_rc);
+		w.carry_agg = (RunMap *)(ent + o_ca);
+		w.carry_in = (unsigned *)(ent + o_ci);
 
 		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
 		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 4 * (size_t)n * w.TS);
@@ -1307,7 +1388,9 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
 	hipLaunchKernelGGL(k_entries, dim3(n), dim3(1024), 0, s, g, w);
 	hipLaunchKernelGGL(k_tokens, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
-	hipLaunchKernelGGL(k_carry, dim3(n), dim3(1024), 0, s, g, w);
+	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_orders_fast, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
 	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
 	hipLaunchKernelGGL(k_lut, dim3(512, n), dim3(256), 0, s, w);
