@@ -16,7 +16,7 @@
 //   k_plan    per image (serial, tiny): header + root image + plane counts
 //             written straight into the stream, the segment schedule, VLI order
 //             after the header.
-//   k_entries per image: an "entry" is (segment, tile).  Symbol counts per
+//   k_entries_* an "entry" is (segment, tile).  Symbol counts per
 //             entry from the histograms, exclusive scans -> first token slot
 //             and refinement rank of every entry.
 //   k_tokens  one wave per entry: classify 64 coefficients per row at the
@@ -109,6 +109,7 @@ struct Work {
 	unsigned long long *lane_bits;     // [n][NCS*64] per 64-token group: bit offset inside its wave's chunk
 	RunMap *carry_agg;                 // [n][NCB] map of each block of 1024 entries
 	unsigned *carry_in;                // [n][NCB] pending run entering the block
+	unsigned *ent_blk;                 // [n][NCB][2] token slots / refinement bits of each block of 1024 entries, then their scan
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
 	long ES, TS, NCS, NGS, NCB;
 	int NT;
@@ -353,74 +354,104 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *wsum, 
 	return woff + inc - v;
 }
 
-constexpr int ENT_PER_THREAD = 4;
+// k_entries_count: one thread per entry, symbol counts from the histograms and the block-local
+// exclusive prefixes of token slots / refinement bits; k_entries_blocks scans the block totals of
+// each image; k_entries_finish adds the block offsets; k_entries_segs derives the per-segment values.
 
-__global__ __launch_bounds__(1024) void k_entries(PackGeom g, Work w)
+constexpr int ENT_BLOCK = 1024;
+
+__global__ __launch_bounds__(ENT_BLOCK) void k_entries_count(PackGeom g, Work w)
+{
+	__shared__ unsigned wsum[16];
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const int K = I.K, E = I.E;
+	if ((int)blockIdx.x * ENT_BLOCK >= E)
+		return;
+	const int *sd = w.seg_desc + (long)img * MAX_SEGS;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
+	unsigned nt = 0, nr = 0;
+	if (e < E) {
+		const int k = seg_of_entry(eb, K, e);
+		int c, l, p;
+		seg_unpack(sd[k], c, l, p);
+		const int j = e - eb[k];
+		const int ntile = g.tile_first[l + 1] - g.tile_first[l];
+		const long ring = (long)g.pixels[l + 1] - g.pixels[l];
+		const long left = ring - (long)j * TILE;
+		const int cnt = left < TILE ? (int)left : TILE;
+		const unsigned short *cum = w.cum + ((long)(img * g.C + c) * w.NT + g.tile_first[l] + j) * NCUM;
+		const int z = cum[p], upto = cum[p + 1];
+		w.ent_zeros[img * w.ES + e] = (unsigned short)z;
+		w.ent_ones[img * w.ES + e] = (unsigned short)(upto - z);
+		w.ent_refs[img * w.ES + e] = (unsigned short)(cnt - upto);
+		nt = (unsigned)(upto - z) + (j == ntile - 1 ? 1u : 0u);   // + the segment's break slot
+		nr = (unsigned)(cnt - upto);
+	}
+	unsigned tt, rt;
+	const unsigned tb = block_excl_scan(nt, wsum, tt);
+	const unsigned rb = block_excl_scan(nr, wsum, rt);
+	if (e < E) {
+		w.ent_tokbase[img * (w.ES + 1) + e] = tb;
+		w.ent_refscum[img * (w.ES + 1) + e] = rb;
+	}
+	if (threadIdx.x == 0) {
+		w.ent_blk[(img * w.NCB + blockIdx.x) * 2] = tt;
+		w.ent_blk[(img * w.NCB + blockIdx.x) * 2 + 1] = rt;
+	}
+}
+
+__global__ __launch_bounds__(ENT_BLOCK) void k_entries_blocks(Work w)
 {
 	__shared__ unsigned wsum[16];
 	const int img = blockIdx.x;
 	ImgInfo &I = w.info[img];
-	const int K = I.K, E = I.E;
-	const int *sd = w.seg_desc + (long)img * MAX_SEGS;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	unsigned short *ones = w.ent_ones + img * w.ES, *zeros = w.ent_zeros + img * w.ES, *refs = w.ent_refs + img * w.ES;
-	unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1);
-	unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+	const int E = I.E;
+	const int nb = (E + ENT_BLOCK - 1) / ENT_BLOCK;
 	unsigned tok_run = 0, ref_run = 0;
-	for (int base = 0; base < E; base += 1024 * ENT_PER_THREAD) {
-		unsigned t_loc[ENT_PER_THREAD], r_loc[ENT_PER_THREAD];
-		unsigned tsum = 0, rsum = 0;
-		for (int q = 0; q < ENT_PER_THREAD; ++q) {
-			const int e = base + threadIdx.x * ENT_PER_THREAD + q;
-			unsigned nt = 0, nr = 0;
-			if (e < E) {
-				const int k = seg_of_entry(eb, K, e);
-				int c, l, p;
-				seg_unpack(sd[k], c, l, p);
-				const int j = e - eb[k];
-				const int ntile = g.tile_first[l + 1] - g.tile_first[l];
-				const long ring = (long)g.pixels[l + 1] - g.pixels[l];
-				const long left = ring - (long)j * TILE;
-				const int cnt = left < TILE ? (int)left : TILE;
-				const unsigned short *cum = w.cum + ((long)(img * g.C + c) * w.NT + g.tile_first[l] + j) * NCUM;
-				const int z = cum[p], upto = cum[p + 1];
-				zeros[e] = (unsigned short)z;
-				ones[e] = (unsigned short)(upto - z);
-				refs[e] = (unsigned short)(cnt - upto);
-				nt = (unsigned)(upto - z) + (j == ntile - 1 ? 1u : 0u);   // + the segment's break slot
-				nr = (unsigned)(cnt - upto);
-			}
-			t_loc[q] = tsum;
-			r_loc[q] = rsum;
-			tsum += nt;
-			rsum += nr;
-		}
+	for (int b0 = 0; b0 < nb; b0 += ENT_BLOCK) {
+		const int b = b0 + threadIdx.x;
+		unsigned *slot = w.ent_blk + (img * w.NCB + b) * 2;
+		const unsigned t = b < nb ? slot[0] : 0u, r = b < nb ? slot[1] : 0u;
 		unsigned tt, rt;
-		const unsigned tb = block_excl_scan(tsum, wsum, tt);
-		const unsigned rb = block_excl_scan(rsum, wsum, rt);
-		for (int q = 0; q < ENT_PER_THREAD; ++q) {
-			const int e = base + threadIdx.x * ENT_PER_THREAD + q;
-			if (e < E) {
-				tokbase[e] = tok_run + tb + t_loc[q];
-				refscum[e] = ref_run + rb + r_loc[q];
-			}
+		const unsigned tb = block_excl_scan(t, wsum, tt);
+		const unsigned rb = block_excl_scan(r, wsum, rt);
+		if (b < nb) {
+			slot[0] = tok_run + tb;
+			slot[1] = ref_run + rb;
 		}
 		tok_run += tt;
 		ref_run += rt;
 	}
 	if (threadIdx.x == 0) {
-		tokbase[E] = tok_run;
-		refscum[E] = ref_run;
+		w.ent_tokbase[img * (w.ES + 1) + E] = tok_run;
+		w.ent_refscum[img * (w.ES + 1) + E] = ref_run;
 		I.T = tok_run + 1;   // + final flush (encode.c:221)
 	}
-	__syncthreads();
-	__threadfence_block();
-	unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
-	unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	for (int k = threadIdx.x; k < K; k += 1024) {
-		srefs[k] = refscum[eb[k + 1]] - refscum[eb[k]];
+}
+
+__global__ __launch_bounds__(ENT_BLOCK) void k_entries_finish(Work w)
+{
+	const int img = blockIdx.y;
+	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
+	if (e >= w.info[img].E)
+		return;
+	const unsigned *slot = w.ent_blk + (img * w.NCB + blockIdx.x) * 2;
+	w.ent_tokbase[img * (w.ES + 1) + e] += slot[0];
+	w.ent_refscum[img * (w.ES + 1) + e] += slot[1];
+}
+
+__global__ __launch_bounds__(ENT_BLOCK) void k_entries_segs(Work w)
+{
+	const int img = blockIdx.x;
+	const int K = w.info[img].K;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1), *refscum = w.ent_refscum + img * (w.ES + 1);
+	for (int k = threadIdx.x; k < K; k += ENT_BLOCK) {
+		w.seg_refs[(long)img * MAX_SEGS + k] = refscum[eb[k + 1]] - refscum[eb[k]];
 		const int last = eb[k + 1] - 1;
-		btok[k] = tokbase[last] + ones[last];
+		w.brk_tok[(long)img * MAX_SEGS + k] = tokbase[last] + w.ent_ones[img * w.ES + last];
 	}
 }
 
@@ -518,7 +549,7 @@ __device__ __forceinline__ RunMap compose(RunMap a, RunMap b)   // a then b
 // token), k_carry_apply redoes the block-local scan from the block's entry state and patches
 // the tokens.
 
-constexpr int CARRY_BLOCK = 1024;
+constexpr int CARRY_BLOCK = ENT_BLOCK;   // both scans cut the entries into the same blocks (Work::NCB)
 
 __device__ __forceinline__ RunMap carry_map_of(const Work &w, const ImgInfo &I, int img, int e, bool &has_one, bool &seg_end, bool &refs)
 {
@@ -1338,6 +1369,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_rc = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_ca = take(sizeof(RunMap) * (size_t)n * w.NCB);
 		const size_t o_ci = take(sizeof(unsigned) * (size_t)n * w.NCB);
+		const size_t o_ek = take(sizeof(unsigned) * 2 * (size_t)n * w.NCB);
 		char *ent = (char *)dwtx_scratch(ctx, SLOT_PK_ENT, off);
 		if (!ent)
 			return DWTX_ERR_NOMEM;
@@ -1349,6 +1381,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.ent_refscum = (unsigned *)(ent + o_rc);
 		w.carry_agg = (RunMap *)(ent + o_ca);
 		w.carry_in = (unsigned *)(ent + o_ci);
+		w.ent_blk = (unsigned *)(ent + o_ek);
 
 		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
 		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 4 * (size_t)n * w.TS);
@@ -1386,7 +1419,10 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 
 	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
-	hipLaunchKernelGGL(k_entries, dim3(n), dim3(1024), 0, s, g, w);
+	hipLaunchKernelGGL(k_entries_count, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, g, w);
+	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_tokens, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
