@@ -28,10 +28,15 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 	if (!a || !b)
 		return DWTX_ERR_NOMEM;
 	int rc;
-	if ((rc = dwtx_planes_from_pixels(ctx, a, dev_pix, W, H, C, n)))       // encode.c:155-156
-		return rc;
-	if ((rc = dwtx_transformation_fwd(ctx, b, a, W, H, n * C)))            // encode.c:159
-		return rc;
+	if (C == 1 && dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H)) {
+		if ((rc = dwtx_fwd_gray8(ctx, b, dev_pix, W, H, n)))                   // encode.c:155-159 in one pass
+			return rc;
+	} else {
+		if ((rc = dwtx_planes_from_pixels(ctx, a, dev_pix, W, H, C, n)))       // encode.c:155-156
+			return rc;
+		if ((rc = dwtx_transformation_fwd(ctx, b, a, W, H, n * C)))            // encode.c:159
+			return rc;
+	}
 	if ((rc = dwtx_linearization(ctx, a, b, W, H, n * C)))                 // encode.c:160
 		return rc;
 	return dwtx_encode_planes(ctx, a, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
@@ -88,6 +93,8 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		int r;
 		if ((r = dwtx_reconstruction(ctx, pyr, lin, miss, lo, W, H, C, count)))              // decode.c:257
 			return r;
+		if (C == 1 && dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
+			return dwtx_inv_gray8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, count);   // decode.c:258-264
 		if ((r = dwtx_transformation_inv(ctx, img, pyr, ow, oh, count * C)))                 // decode.c:258
 			return r;
 		if (count == 1 || (size_t)ow * oh * C == pix_stride)

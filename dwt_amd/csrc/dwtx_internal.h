@@ -47,6 +47,13 @@ enum {
 	SLOT_LIFT_B = 1,
 };
 
+// lift.hip: the finest lifting level of gray images reads / writes 8-bit pixels itself (the widening of
+// pnm.h:69-74 and the clamp of pnm.h:108 fused into the transform).  dwtx_gray8_ok says whether the
+// shape allows it; image i of the inverse is written at pix + i*image_stride.
+bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
+int dwtx_fwd_gray8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int n);
+int dwtx_inv_gray8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int n);
+
 // C truncating division by 2 and 4 on the device (cdf53.h:13,20 use `/`)
 __device__ __forceinline__ int tdiv2(int a) { return (a + (int)((unsigned)a >> 31)) >> 1; }
 __device__ __forceinline__ int tdiv4(int a) { return (a + ((a >> 31) & 3)) >> 2; }

@@ -32,6 +32,8 @@ struct LevelArgs {
 	int *det;        long det_ps;  int dpitch;  // Mallat pyramid: HL at (w2+x, y), LH at (x, h2+y), HH at (w2+x, h2+y)
 	int w, h, w2, h2;
 	int rpw;          // output row pairs per wave strip
+	const uint8_t *src8;   // forward, finest level of a gray image: 8-bit pixels instead of src (pnm.h:69-74 widening fused)
+	uint8_t *dst8;         // inverse, finest level of a gray image: clamped 8-bit pixels instead of ll (pnm.h:108 fused)
 };
 
 // ---------------------------------------------------------------- forward ---
@@ -268,6 +270,20 @@ __device__ __forceinline__ FwdRaw fwd_load_w(const int *__restrict__ row, int q,
 	return r;
 }
 
+__device__ __forceinline__ FwdRaw fwd_load_w(const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid)
+{
+	FwdRaw r;
+	const unsigned v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
+	r.x = make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
+	r.xr = 0;
+	r.left = make_int2(0, 0);
+	if (lane == 63 && valid && q + 1 < nquads)
+		r.xr = row[4 * q + 4];
+	if (lane == 0 && valid && q > 0)
+		r.left = make_int2(row[4 * q - 2], row[4 * q - 1]);
+	return r;
+}
+
 __device__ __forceinline__ void fwd_lift_w(const FwdRaw &r, int q, int lane, int nquads, I2 &lo, I2 &hi)
 {
 	int xr = __shfl_down(r.x.x, 1);
@@ -305,6 +321,14 @@ __device__ __forceinline__ void st2(int *p, I2 v)
 	*reinterpret_cast<int2 *>(p) = make_int2(v.a, v.b);
 }
 
+template <typename SrcT>
+__device__ __forceinline__ const SrcT *fwd_src(const LevelArgs &a);
+template <>
+__device__ __forceinline__ const int *fwd_src<int>(const LevelArgs &a) { return a.src; }
+template <>
+__device__ __forceinline__ const uint8_t *fwd_src<uint8_t>(const LevelArgs &a) { return a.src8; }
+
+template <typename SrcT>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	const bool valid = q < A.nquads;
-	const int *src = a.src + plane * a.src_ps;
+	const SrcT *src = fwd_src<SrcT>(a) + plane * a.src_ps;
 	int *ll = a.ll + plane * a.ll_ps;
 	int *det = a.det + plane * a.det_ps;
 
@@ -396,7 +420,19 @@ __device__ __forceinline__ I2 to_i2(int2 v)
 }
 
 // horizontal inverse of one output row for this lane's two pairs
-__device__ __forceinline__ void inv_row_w(int *__restrict__ row, int qd, int nquads, bool writes, I2 lo, I2 hi)
+__device__ __forceinline__ void inv_store_w(int *__restrict__ row, int qd, int e0, int o0, int e1, int o1)
+{
+	*reinterpret_cast<int4 *>(row + 4 * qd) = make_int4(e0, o0, e1, o1);
+}
+
+__device__ __forceinline__ void inv_store_w(uint8_t *__restrict__ row, int qd, int e0, int o0, int e1, int o1)
+{
+	auto c8 = [](int v) { return (unsigned)(v < 0 ? 0 : v > 255 ? 255 : v); };
+	*reinterpret_cast<unsigned *>(row + 4 * qd) = c8(e0) | (c8(o0) << 8) | (c8(e1) << 16) | (c8(o1) << 24);
+}
+
+template <typename DstT>
+__device__ __forceinline__ void inv_row_w(DstT *__restrict__ row, int qd, int nquads, bool writes, I2 lo, I2 hi)
 {
 	int hl = __shfl_up(hi.b, 1);
 	if (qd <= 0)
@@ -409,9 +445,17 @@ __device__ __forceinline__ void inv_row_w(int *__restrict__ row, int qd, int nqu
 	const int o0 = hi.a + tdiv2(e0 + e1);
 	const int o1 = hi.b + tdiv2(e1 + er);
 	if (writes)
-		*reinterpret_cast<int4 *>(row + 4 * qd) = make_int4(e0, o0, e1, o1);
+		inv_store_w(row, qd, e0, o0, e1, o1);
 }
 
+template <typename DstT>
+__device__ __forceinline__ DstT *inv_dst(const LevelArgs &a);
+template <>
+__device__ __forceinline__ int *inv_dst<int>(const LevelArgs &a) { return a.ll; }
+template <>
+__device__ __forceinline__ uint8_t *inv_dst<uint8_t>(const LevelArgs &a) { return a.dst8; }
+
+template <typename DstT>
 __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -426,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	const bool writes = valid && lane >= 1 && lane <= INV_PAIRS;
 	const int *llp = a.src + plane * a.src_ps;
 	const int *det = a.det + plane * a.det_ps;
-	int *dst = a.ll + plane * a.ll_ps;
+	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
 	const bool h_odd = a.h & 1;
 
 	auto even_of = [&](int j, I2 s, I2 dprev, I2 dcur) {
@@ -767,9 +811,10 @@ static int pick_rpw(int strips_x, int h2, int nplanes)
 	return rpw;
 }
 
-extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes)
+// in8 != nullptr: the planes are 8-bit gray images (W*H bytes each); needs a finest level the wide kernel takes
+static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int W, int H, int nplanes)
 {
-	if (!ctx || !out || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
+	if (!ctx || !out || (!in && !in8) || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
 	int ws[DWTX_MAX_LEVELS + 2], hs[DWTX_MAX_LEVELS + 2];
 	const int T = lift_steps(W, H, ws, hs);
@@ -796,6 +841,8 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 	const int *src = in;
 	long src_ps = full_ps;
 	int spitch = W;
+	if (in8 && tail_from == 0)
+		return DWTX_ERR_ARG;
 	auto ll_dest = [&](int k, int *&p, long &ps, int &pitch) {   // destination of the ws[k]*hs[k] LL band
 		if (k == T) {
 			p = out;
@@ -833,16 +880,22 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 		a.h = hs[t];
 		a.w2 = ws[t + 1];
 		a.h2 = hs[t + 1];
-		a.src = src;
+		const bool bytes_in = in8 && t == 0;
+		a.src = bytes_in ? nullptr : src;
+		a.src8 = bytes_in ? in8 : nullptr;
+		a.dst8 = nullptr;
 		a.src_ps = src_ps;
 		a.spitch = spitch;
 		ll_dest(t + 1, a.ll, a.ll_ps, a.llpitch);
 		a.det = out;
 		a.det_ps = full_ps;
 		a.dpitch = W;
-		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 && aligned_to(a.src, 16) &&
+		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 &&
+			(bytes_in ? aligned_to(a.src8, 4) : aligned_to(a.src, 16)) &&
 			a.llpitch % 2 == 0 && a.ll_ps % 2 == 0 && aligned_to(a.ll, 8) &&
 			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
+		if (bytes_in && !wide)
+			return DWTX_ERR_ARG;   // callers check dwtx_gray8_ok() first
 		if (wide) {
 			LevelArgsW A;
 			A.nquads = a.w / 4;
@@ -850,7 +903,10 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
-			hipLaunchKernelGGL(k_fwd_level_w, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			if (bytes_in)
+				hipLaunchKernelGGL(k_fwd_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else
+				hipLaunchKernelGGL(k_fwd_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, 64);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
@@ -866,9 +922,30 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 	return DWTX_OK;
 }
 
-extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes)
+extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes)
 {
-	if (!ctx || !out || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
+	if (!in)
+		return DWTX_ERR_ARG;
+	return lift_fwd(ctx, out, in, nullptr, W, H, nplanes);
+}
+
+// Can the finest level of a W*H gray image read / write 8-bit pixels directly?  (wide kernel, not the LDS tail)
+bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride)
+{
+	return W % 4 == 0 && (W > TAIL_MAX || H > TAIL_MAX) && image_stride % 4 == 0 && aligned_to(pix, 4);
+}
+
+int dwtx_fwd_gray8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int n)
+{
+	if (!pix || W < 2 || H < 2 || !dwtx_gray8_ok(W, H, pix, (size_t)W * H))
+		return DWTX_ERR_ARG;
+	return lift_fwd(ctx, out, nullptr, pix, W, H, n);
+}
+
+// out8 != nullptr: the finest level writes clamped 8-bit pixels, image i at out8 + i*out8_ps
+static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, const int32_t *in, int W, int H, int nplanes)
+{
+	if (!ctx || (!out && !out8) || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
 	int ws[DWTX_MAX_LEVELS + 2], hs[DWTX_MAX_LEVELS + 2];
 	const int T = lift_steps(W, H, ws, hs);
@@ -896,6 +973,8 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 		ta.src = nullptr;
 		ta.src_ps = 0;
 		ta.spitch = 0;
+		if (t == 0 && out8)
+			return DWTX_ERR_ARG;
 		ta.dst = t == 0 ? out : tmp[t & 1];
 		ta.dst_ps = t == 0 ? full_ps : (long)ws[t] * hs[t];
 		ta.dpitch2 = t == 0 ? W : ws[t];
@@ -926,7 +1005,15 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 			a.src_ps = (long)a.w2 * a.h2;
 			a.spitch = a.w2;
 		}
-		if (t == 0) {
+		const bool bytes_out = out8 && t == 0;
+		a.src8 = nullptr;
+		a.dst8 = nullptr;
+		if (bytes_out) {
+			a.ll = nullptr;
+			a.dst8 = out8;
+			a.ll_ps = out8_ps;
+			a.llpitch = W;
+		} else if (t == 0) {
 			a.ll = out;
 			a.ll_ps = full_ps;
 			a.llpitch = W;
@@ -938,9 +1025,12 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 		a.det = const_cast<int *>(in);
 		a.det_ps = full_ps;
 		a.dpitch = W;
-		const bool wide = a.w % 4 == 0 && a.llpitch % 4 == 0 && a.ll_ps % 4 == 0 && aligned_to(a.ll, 16) &&
+		const bool wide = a.w % 4 == 0 && a.llpitch % 4 == 0 && a.ll_ps % 4 == 0 &&
+			(bytes_out ? aligned_to(a.dst8, 4) : aligned_to(a.ll, 16)) &&
 			a.spitch % 2 == 0 && a.src_ps % 2 == 0 && aligned_to(a.src, 8) &&
 			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
+		if (bytes_out && !wide)
+			return DWTX_ERR_ARG;
 		if (wide) {
 			LevelArgsW A;
 			A.nquads = a.w / 4;
@@ -948,7 +1038,10 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
-			hipLaunchKernelGGL(k_inv_level_w, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			if (bytes_out)
+				hipLaunchKernelGGL(k_inv_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else
+				hipLaunchKernelGGL(k_inv_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, INV_PAIRS);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
@@ -958,4 +1051,18 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 		DWTX_LAUNCH_CHECK();
 	}
 	return DWTX_OK;
+}
+
+extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes)
+{
+	if (!out)
+		return DWTX_ERR_ARG;
+	return lift_inv(ctx, out, nullptr, 0, in, W, H, nplanes);
+}
+
+int dwtx_inv_gray8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int n)
+{
+	if (!pix || W < 2 || H < 2 || !dwtx_gray8_ok(W, H, pix, image_stride))
+		return DWTX_ERR_ARG;
+	return lift_inv(ctx, nullptr, pix, (long)image_stride, in, W, H, n);
 }

@@ -32,11 +32,17 @@ def test_smpte_files_and_stderr(tmp_path):
 
 def test_stdin_stdout_pipes():
     src = open(SMPTE, "rb").read()
+    want = open(os.path.join(orc.GOLDEN, "smpte.dwt"), "rb").read()
     r = run(ENC, "-", "-", stdin=src)
-    assert r.returncode == 0 and r.stdout == open(os.path.join(orc.GOLDEN, "smpte.dwt"), "rb").read()
-    r2 = run(DEC, "-", "-", stdin=r.stdout)
-    assert r2.returncode == 0 and r2.stdout.startswith(b"P6 320 240 255\n")
-    assert r2.stdout[len(b"P6 320 240 255\n"):] == orc.read_pnm(SMPTE).tobytes()
+    assert r.returncode == 0, r.stderr[-400:]
+    assert len(r.stdout) == len(want), (len(r.stdout), r.stderr[-400:])
+    assert r.stdout == want
+    r2 = run(DEC, "-", "-", stdin=want)
+    assert r2.returncode == 0, r2.stderr[-400:]
+    assert r2.stdout.startswith(b"P6 320 240 255\n"), r2.stdout[:32]
+    body, pix = r2.stdout[len(b"P6 320 240 255\n"):], orc.read_pnm(SMPTE).tobytes()
+    assert len(body) == len(pix), (len(body), r2.stderr[-400:])
+    assert body == pix, sum(a != b for a, b in zip(body, pix))
 
 
 def test_capacity_and_pixels_arguments(tmp_path):
