@@ -59,13 +59,17 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 	int *b = (int *)dwtx_scratch(ctx, SLOT_CD_B, bytes);
 	if (!a || !b)
 		return DWTX_ERR_NOMEM;
-	if ((rc = dwtx_decode_planes(ctx, a, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info)))
-		return rc;
-	bool uniform = true;
-	for (int i = 0; i < n; ++i)
-		uniform = uniform && !host_info[i].status && host_info[i].level == host_info[0].level &&
-			memcmp(host_info[i].missing, host_info[0].missing, sizeof(host_info[0].missing)) == 0;
 	const size_t plane_ints = (size_t)W * H;
+	// scratch both parts of the batch will ask for, sized once for the larger request
+	{
+		const size_t part_planes = (size_t)(n < 4 ? n : n - n / 2) * C;
+		const size_t w1 = (W + 1) / 2, h1 = (H + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
+		if (!dwtx_scratch(ctx, SLOT_CD_INFO, sizeof(int) * 48 * (size_t)n) ||
+			!dwtx_scratch(ctx, SLOT_LIFT_A, sizeof(int) * w1 * h1 * part_planes) ||
+			!dwtx_scratch(ctx, SLOT_LIFT_B, sizeof(int) * w2 * h2 * part_planes))
+			return DWTX_ERR_NOMEM;
+	}
+	// reconstruction -> inverse transform -> pixels for images [first, first+count), queued on ctx->stream
 	auto finish = [&](int first, int count) -> int {
 		const dwtx_decode_info &I = host_info[first];
 		const int lo = I.level + 1;                                          // decode.c:251
@@ -77,9 +81,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		for (int k = 0; k < 48; ++k)
 			biased = biased || I.missing[k] >= 2;
 		if (biased) {
-			miss = (int *)dwtx_scratch(ctx, SLOT_CD_INFO, sizeof(int) * 48 * (size_t)count);
-			if (!miss)
-				return DWTX_ERR_NOMEM;
+			miss = (int *)dwtx_scratch(ctx, SLOT_CD_INFO, sizeof(int) * 48 * (size_t)n) + 48 * (size_t)first;
 			for (int i = 0; i < count; ++i) {
 				int r = (int)hipMemcpyAsync(miss + 48 * i, host_info[first + i].missing, sizeof(int) * 48,
 					hipMemcpyHostToDevice, ctx->stream);
@@ -105,12 +107,24 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 				return r;
 		return DWTX_OK;
 	};
-	if (uniform)
-		return finish(0, n);
-	for (int i = 0; i < n; ++i)
-		if (!host_info[i].status && (rc = finish(i, 1)))
-			return rc;
-	return DWTX_OK;
+	// called by the decoder for each part of the batch as soon as its coefficients are on their way
+	auto part = [&](int first, int count) -> int {
+		bool uniform = true;
+		for (int i = first; i < first + count; ++i)
+			uniform = uniform && !host_info[i].status && host_info[i].level == host_info[first].level &&
+				memcmp(host_info[i].missing, host_info[first].missing, sizeof(host_info[first].missing)) == 0;
+		if (uniform)
+			return finish(first, count);
+		for (int i = first; i < first + count; ++i) {
+			int r;
+			if (!host_info[i].status && (r = finish(i, 1)))
+				return r;
+		}
+		return DWTX_OK;
+	};
+	using Part = decltype(part);
+	return dwtx_decode_planes_ex(ctx, a, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info,
+		[](void *user, int first, int count) { return (*(Part *)user)(first, count); }, &part);
 }
 
 // ---- host-buffer convenience wrappers (what the CLIs call) --------------------

@@ -54,6 +54,11 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
 int dwtx_fwd_gray8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int n);
 int dwtx_inv_gray8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int n);
 
+// unpack.hip: dwtx_decode_planes with a host callback per finished part of the batch (see there)
+int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
+	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
+	int (*done)(void *user, int first, int count), void *user);
+
 // C truncating division by 2 and 4 on the device (cdf53.h:13,20 use `/`)
 __device__ __forceinline__ int tdiv2(int a) { return (a + (int)((unsigned)a >> 31)) >> 1; }
 __device__ __forceinline__ int tdiv4(int a) { return (a + ((a >> 31) & 3)) >> 2; }

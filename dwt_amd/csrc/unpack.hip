@@ -1111,72 +1111,57 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	const long base = g.pixels[l] + (long)j * TILE;
 	const unsigned *sym = w.symbits + img * w.BW;
 	const unsigned *stream = (const unsigned *)(streams + img * stream_stride);
-	const unsigned long long below = (1ull << lane) - 1ull;
-	unsigned v[ROWS];
+	const int left = (int)(ring1 - base < TILE ? ring1 - base : TILE) - lane;   // row r holds a coefficient iff 64r < left
+	const unsigned idx0 = (unsigned)j * TILE + (unsigned)lane;                  // ring index of this lane's row-0 coefficient
+	unsigned mag[ROWS];
+	unsigned neg = 0;   // bit r: the coefficient of row r is negative
 #pragma unroll
 	for (int r = 0; r < ROWS; ++r)
-		v[r] = 0;
+		mag[r] = 0;
 	for (int p = I.planes[c] - 1; p >= 0; --p) {
 		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
 		if (!k1)
 			continue;
 		const int k = k1 - 1;
-		const unsigned long long sym0 = w.seg_symbase[(long)img * MAX_SEGS + k];
 		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
 		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
 		unsigned rank = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
-		// one word per coefficient and plane — from the symbol bitmap while insignificant, from the
-		// stream once significant.  Ranks need no loaded data, so all 16 loads are issued first.
-		unsigned word[ROWS];
-		unsigned char shift[ROWS];
-		unsigned char kind[ROWS];   // 0 nothing, 1 pass-1 symbol, 2 refinement bit
+		// Both sources are read as one 32-bit word per coefficient and plane: the symbol bitmap (two bits
+		// per symbol; a segment's symbols start on a word boundary) while the coefficient is
+		// insignificant, the stream's refinement block once it is significant.  The address is the
+		// bitmap base plus a lane offset; refinement reads add the uniform distance to their block.
+		const unsigned *sbase = sym + (w.seg_symbase[(long)img * MAX_SEGS + k] >> 4);
+		const unsigned b2s = (unsigned)(b2 & 31);
+		const long rdelta = (const char *)(stream + (b2 >> 5)) - (const char *)sbase;
+		// sel: bits 0-4 shift, bit 5 "pass-1 symbol", bit 6 "has a bit in this plane"
+		unsigned word[ROWS], sel[ROWS];
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
-			const long i = base + r * 64 + lane;
-			const bool in = i < ring1;
-			const bool was_sig = in && (v[r] & 0x7fffffffu) != 0;
-			const unsigned long long nm = __ballot(in && !was_sig);
-			const unsigned r1 = rank + (unsigned)__builtin_popcountll(nm & below);
+			const bool in = 64 * r < left;
+			const bool ns = in && mag[r] == 0;
+			const unsigned long long nm = __ballot(ns);
+			const unsigned r1 = rank + (unsigned)popc_below(nm);
 			rank += (unsigned)__builtin_popcountll(nm);
-			const unsigned *ptr = sym;
-			kind[r] = 0;
-			shift[r] = 0;
-			if (in && !was_sig) {
-				const unsigned long long pos = sym0 + r1;
-				ptr = sym + (pos >> 4);
-				shift[r] = (unsigned char)((pos & 15) * 2);
-				kind[r] = 1;
-			} else if (in) {
-				const unsigned r2 = (unsigned)(i - g.pixels[l]) - r1;   // significant coefficients before this one
-				if (r2 < n2done) {
-					const unsigned long long pos = b2 + r2;
-					ptr = stream + (pos >> 5);
-					shift[r] = (unsigned char)(pos & 31);
-					kind[r] = 2;
-				}
-			}
-			word[r] = *ptr;
+			const unsigned r2 = idx0 + 64u * r - r1;   // significant coefficients before this one
+			const bool rf = in && !ns && r2 < n2done;
+			const unsigned pb = b2s + r2;
+			const unsigned wi = ns ? r1 >> 4 : rf ? pb >> 5 : 0u;
+			sel[r] = ns ? 96u | ((r1 & 15u) << 1) : rf ? 64u | (pb & 31u) : 0u;
+			word[r] = *(const unsigned *)((const char *)sbase + (rf ? rdelta : 0l) + 4l * wi);
 		}
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
-			const unsigned bits = word[r] >> shift[r];
-			if (kind[r] == 1) {
-				if (bits & 1u)
-					v[r] |= (1u << p) | ((bits & 2u) << 30);
-			} else if (kind[r] == 2) {
-				v[r] |= (bits & 1u) << p;
-			}
+			const unsigned bits = word[r] >> (sel[r] & 31u);
+			const unsigned bit = bits & (sel[r] >> 6);
+			mag[r] |= bit << p;
+			neg |= ((bits >> 1) & bit & (sel[r] >> 5)) << r;   // the sign follows a pass-1 one (decode.c:80-85)
 		}
 	}
-	int *dst = lin + (long)plane * g.lin_stride;
+	int *dst = lin + (long)plane * g.lin_stride + base;
 #pragma unroll
-	for (int r = 0; r < ROWS; ++r) {
-		const long i = base + r * 64 + lane;
-		if (i < ring1) {
-			const int mag = (int)(v[r] & 0x1fffffffu);
-			dst[i] = (v[r] >> 31) ? -mag : mag;
-		}
-	}
+	for (int r = 0; r < ROWS; ++r)
+		if (64 * r < left)
+			dst[r * 64 + lane] = ((neg >> r) & 1u) ? -(int)mag[r] : (int)mag[r];
 }
 
 // tile_nonsig starts as the tile's coefficient count
@@ -1199,8 +1184,13 @@ enum { SLOT_UP_SMALL = 12, SLOT_UP_BITS, SLOT_UP_TILES, SLOT_UP_CHUNKS };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
-	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info)
+// `done(user, first, count)` (optional) is called on the host as soon as host_info[first..first+count)
+// is valid and every kernel writing those images' planes has been enqueued on ctx->stream (or
+// ordered before it): the caller can queue its own follow-up work for that part of the batch
+// there while the rest of the batch is still being decoded.
+int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
+	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
+	int (*done)(void *user, int first, int count), void *user)
 {
 	if (!ctx || !lin || !streams || !dev_lens || !host_info || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || W > 65536 ||
 		H > 65536 || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 || (stream_stride & 7) || stream_stride < 64)
@@ -1410,7 +1400,7 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
 		if ((rc = pre(s, 0, n)) || (rc = walk(s, 0, n)) || (rc = post(s, 0, n)))
 			return rc;
-		return DWTX_OK;
+		return done ? done(user, 0, n) : DWTX_OK;
 	}
 	// The token walk is one wave per image and leaves the chip idle: run the two halves of the batch
 	// on two streams, the second one half a pipeline behind, so that each half's walk overlaps the
@@ -1428,9 +1418,17 @@ extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *st
 	DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
 	if ((rc = walk(s, 0, na)) || (rc = pre(ctx->aux, na, n - na)) || (rc = walk(ctx->aux, na, n - na)))
 		return rc;
-	if ((rc = post(s, 0, na)) || (rc = post(ctx->aux, na, n - na)))
+	if ((rc = post(s, 0, na)) || (done && (rc = done(user, 0, na))))   // the first half's follow-up overlaps the second half's walk
+		return rc;
+	if ((rc = post(ctx->aux, na, n - na)))
 		return rc;
 	DWTX_HIP(hipEventRecord(ctx->ev[1], ctx->aux));
 	DWTX_HIP(hipStreamWaitEvent(s, ctx->ev[1], 0));
-	return DWTX_OK;
+	return done ? done(user, na, n - na) : DWTX_OK;
+}
+
+extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
+	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info)
+{
+	return dwtx_decode_planes_ex(ctx, lin, streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info, nullptr, nullptr);
 }
