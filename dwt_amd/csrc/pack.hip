@@ -960,15 +960,32 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 	FastTile &tile = tiles[wv];
 	const long S = wave * FSUBS - 1 + lane;          // this lane's 64-token group (lane 0: predecessor only)
 	const long tfirst = (wave * FSUBS - 1) * SUB;    // first token of the wave's window (-64 for wave 0)
-	const int lsub = lane >> 4, ltok = lane & 15;
+	// a lane moves four consecutive tokens of one group at a time: 16 bytes of runs, 4 bytes of flags
+	const int vsub = lane >> 2, q4 = (lane & 3) * 4;
 	auto load_tile = [&](int qt) {
-#pragma unroll 4
-		for (int k = 0; k < 16; ++k) {
-			const int sub = k * 4 + lsub;
-			const long t = tfirst + (long)sub * SUB + qt * QT + ltok;
-			const bool in = t >= 0 && t < T;
-			tile.run[sub][ltok] = in ? run[t] : 0u;
-			tile.flag[sub][ltok] = in ? flag[t] : (unsigned char)F_VOID;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int sub = k * 16 + vsub;
+			const long t = tfirst + (long)sub * SUB + qt * QT + q4;   // multiple of 4, like every image's token base
+			uint4 r = make_uint4(0u, 0u, 0u, 0u);
+			unsigned f = F_VOID * 0x01010101u;
+			if (t >= 0 && t < T) {
+				r = *reinterpret_cast<const uint4 *>(run + t);
+				f = *reinterpret_cast<const unsigned *>(flag + t);
+				const long left = T - t;   // tokens past T are stale scratch
+				if (left < 4) {
+					r.w = 0u;
+					r.z = left > 2 ? r.z : 0u;
+					r.y = left > 1 ? r.y : 0u;
+					const unsigned keep = left > 2 ? 0x00ffffffu : left > 1 ? 0x0000ffffu : 0x000000ffu;
+					f = (f & keep) | ((F_VOID * 0x01010101u) & ~keep);
+				}
+			}
+			tile.run[sub][q4] = r.x;
+			tile.run[sub][q4 + 1] = r.y;
+			tile.run[sub][q4 + 2] = r.z;
+			tile.run[sub][q4 + 3] = r.w;
+			*reinterpret_cast<unsigned *>(&tile.flag[sub][q4]) = f;
 		}
 	};
 	int lo = 0, hi = 31;
@@ -1045,13 +1062,23 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 				rawbits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + qt * QT + t))];
 		}
 		__builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-		for (int k = 0; k < 16; ++k) {
-			const int sub = k * 4 + lsub;
-			const long t = tfirst + (long)sub * SUB + qt * QT + ltok;
-			if (sub >= 1 && t < T) {
-				ord[t] = tile.ord[sub][ltok];
-				off[t] = tile.off[sub][ltok];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int sub = k * 16 + vsub;
+			const long t = tfirst + (long)sub * SUB + qt * QT + q4;
+			if (sub < 1 || t >= T)
+				continue;
+			const unsigned o4 = *reinterpret_cast<const unsigned *>(&tile.ord[sub][q4]);
+			const unsigned f01 = *reinterpret_cast<const unsigned *>(&tile.off[sub][q4]);
+			const unsigned f23 = *reinterpret_cast<const unsigned *>(&tile.off[sub][q4 + 2]);
+			if (t + 4 <= T) {
+				*reinterpret_cast<unsigned *>(ord + t) = o4;
+				*reinterpret_cast<uint2 *>(off + t) = make_uint2(f01, f23);
+			} else {
+				for (int e = 0; e < (int)(T - t); ++e) {
+					ord[t + e] = tile.ord[sub][q4 + e];
+					off[t + e] = tile.off[sub][q4 + e];
+				}
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -1323,7 +1350,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
 	w.ES = (long)NT * C * MAX_PLANES + 16;
-	w.TS = (long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8;
+	w.TS = ((long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8 + 63) / 64 * 64;   // multiple of 64: every image's token arrays start vector-aligned
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
 	w.NGS = (w.NCS + GROUP - 1) / GROUP;
 	w.NCB = (w.ES + CARRY_BLOCK - 1) / CARRY_BLOCK;
