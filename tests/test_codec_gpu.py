@@ -146,3 +146,37 @@ def test_device_resident_roundtrip(ctx):
     host = pix.cpu().numpy()
     for i in range(n):
         assert streams[i, : int(lens[i])].cpu().numpy().tobytes() == orc.encode(host[i])[0]
+
+
+@pytest.mark.parametrize("shape", [(117, 200, 1), (72, 68, 1), (64, 128, 1), (255, 512, 1), (600, 36, 1)])
+def test_gray_pixels_straight_into_the_lifting(ctx, shape):
+    """W % 4 == 0 gray images skip the int widening / clamp passes (pnm.h:69-74,108 fused into the finest
+    lifting level); same bytes, full and cut short, with odd heights and levels that fall back."""
+    H, W, Cn = shape
+    pix = orc.synth(W, H, Cn, 3, 0)
+    full, _ = ctx.encode(pix)
+    assert full == orc.encode(pix)[0]
+    assert (ctx.decode(full) == pix).all()
+    for cap in (len(full) // 7, len(full) // 2):
+        want = orc.decode(full[:cap])
+        got = ctx.decode(full[:cap])
+        assert (want is None and got is None) or (got.shape == want.shape and (got == want).all())
+    for px in (0, 300, 20000):
+        want = orc.decode(full, px)
+        got = ctx.decode(full, px)
+        assert got.shape == want.shape and (got == want).all()
+
+
+def test_gray_batch_both_halves_and_mixed_lengths(ctx):
+    """n >= 4 takes the two-stream decoder whose halves queue their own inverse transform; odd n, one
+    truncated member (different output size) and clamping on noise."""
+    n, H, W = 7, 120, 256
+    pix = np.stack([orc.synth(W, H, 1, 60 + i, i & 1)[..., 0] for i in range(n)])[..., None]
+    streams, _ = ctx.encode(pix)
+    for i in range(n):
+        assert streams[i] == orc.encode(pix[i])[0]
+    streams[5] = streams[5][: len(streams[5]) // 3]
+    outs = ctx.decode(streams)
+    for i in range(n):
+        want = orc.decode(streams[i])
+        assert outs[i].shape == want.shape and (outs[i] == want).all()
