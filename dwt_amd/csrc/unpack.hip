@@ -647,17 +647,25 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			off = (int)(entry & 0xff);
 			o = (int)(entry >> 8);
 		}
-		// symbol positions only grow: gather the bits of one bitmap word before touching memory
+		// Symbol positions only grow: gather the bits of one bitmap word before touching memory.  The
+		// words strictly inside this piece's symbol range belong to it alone (neighbouring pieces and the
+		// walker's own tokens can only share its first and last word), so only those two need atomics.
 		long cur = -1;
 		unsigned acc = 0;
+		bool first = true;
 		chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
 			if (!left)
 				return false;
 			pos += run;
 			const long wi = (long)(pos >> 4);
 			if (wi != cur) {
-				if (acc)
-					atomicOr(sym + cur, acc);
+				if (acc) {
+					if (first)
+						atomicOr(sym + cur, acc);
+					else
+						sym[cur] = acc;
+					first = false;
+				}
 				cur = wi;
 				acc = 0;
 			}
