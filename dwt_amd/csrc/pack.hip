@@ -488,8 +488,11 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 	const int *sx = w.segidx + ((long)img * 48 + c * 16 + l) * MAX_PLANES;
 	unsigned *tok_run = w.tok_run + img * w.TS;
 	unsigned char *tok_flag = w.tok_flag + img * w.TS;
-	const unsigned long long below = (1ull << lane) - 1ull;
 	const int pstart = I.planes[c] > 0 ? I.planes[c] - 1 : 0;
+	// zeros before each one of the current row, by rank of the one: the run of a one is the difference
+	// to its predecessor's count (LDS hand-over instead of per-lane 64-bit mask arithmetic)
+	__shared__ unsigned zbefore[4][64];
+	unsigned *zb = zbefore[threadIdx.x >> 6];
 	for (int p = pstart; p >= 0; --p) {
 		const int k1 = sx[p];
 		if (!k1)
@@ -500,24 +503,21 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
 			const unsigned mag = m[r] & 0x7fffffffu;
-			const bool refine = in[r] && (mag >> (p + 1)) != 0;
+			const bool refine = (mag >> (p + 1)) != 0;
 			const bool one = in[r] && !refine && ((mag >> p) & 1u);
 			const bool zero = in[r] && !refine && !one;
 			const unsigned long long om = __ballot(one), zm = __ballot(zero);
-			if (one) {
-				const unsigned long long prev = om & below;
-				unsigned run;
-				if (prev) {
-					const int hb = 63 - __builtin_clzll(prev);
-					run = (unsigned)__builtin_popcountll(zm & below & ~((2ull << hb) - 1ull));
-				} else {
-					run = pending + (unsigned)__builtin_popcountll(zm & below);
-				}
-				const unsigned idx = tb + (unsigned)__builtin_popcountll(prev);
-				tok_run[idx] = run;
-				tok_flag[idx] = (unsigned char)(F_HAS_SIGN | ((m[r] >> 31) ? F_SIGN : 0));
-			}
 			if (om) {
+				const unsigned z = (unsigned)popc_below(zm), k = (unsigned)popc_below(om);
+				if (one)
+					zb[k] = z;
+				__builtin_amdgcn_wave_barrier();
+				if (one) {
+					const unsigned run = k ? z - zb[k - 1] : pending + z;
+					tok_run[tb + k] = run;
+					tok_flag[tb + k] = (unsigned char)(F_HAS_SIGN | ((m[r] >> 31) ? F_SIGN : 0));
+				}
+				__builtin_amdgcn_wave_barrier();
 				const int last = 63 - __builtin_clzll(om);
 				pending = last == 63 ? 0u : (unsigned)__builtin_popcountll(zm >> (last + 1));
 				tb += (unsigned)__builtin_popcountll(om);
@@ -1092,72 +1092,108 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 }
 
 // ------------------------------------------------------------------ k_emit ---
-// bits.h:58-78: one lane per token.  The token's position is chunk base + its
-// lane-group's offset + its own offset (+ the refinement blocks of earlier break
-// tokens of the same group); its at most 62 code bits go out with atomicOr.
+// bits.h:58-78: one lane per four consecutive tokens, one wave per 256.  A token's position is
+// chunk base + its 64-token group's offset + its own offset (+ the refinement blocks of earlier
+// break tokens of the same group).  The four codes of a lane are adjacent in the stream unless a
+// break lies between them, so they are glued into one bit string first; the strings of a wave
+// are merged in an LDS window, and each stream word costs one global atomic per wave.
 
-constexpr int COMB = 192;   // words: 64 tokens of up to 62 bits, plus slack
+constexpr int COMB = 192;      // words of the LDS window (typical: 256 tokens of ~4 bits = 32 words)
+constexpr int EMIT_TOK = 4;    // tokens per lane
 
 __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_words)
 {
 	__shared__ unsigned comb[4][COMB];
 	const int lane = threadIdx.x & 63;
-	const long group = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 64 consecutive tokens
+	const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
-	const unsigned T = I.T;
-	if (group * SUB >= (long)T)
+	const long T = I.T;
+	const long t0 = wave * (64 * EMIT_TOK) + lane * EMIT_TOK;   // multiple of 4, like the token arrays' bases
+	if (wave * (64 * EMIT_TOK) >= T)
 		return;
-	const long t = group * SUB + lane;
-	const bool in = t < (long)T;
-	const unsigned f = in ? w.tok_flag[img * w.TS + t] : F_VOID;
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	const long chunk = group / (w.slow[img] ? 64 : FSUBS);
-	unsigned long long pos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[img * w.NCS * 64 + group] +
-		(in ? w.tok_off[img * w.TS + t] : 0);
-	// break tokens are followed by their segment's refinement block: later tokens of the group move up
-	unsigned long long bm = __ballot(in && (f & F_BREAK));
-	long myseg = -1;
-	while (bm) {
-		const int j = __builtin_ctzll(bm);
-		bm &= bm - 1;
-		const long k = find_break_seg(btok, I.K, (unsigned)(group * SUB + j));
-		if (lane > j)
-			pos += srefs[k];
-		if (lane == j)
-			myseg = k;
+	unsigned f4 = F_VOID * 0x01010101u, o4 = 0;
+	uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
+	uint2 off4 = make_uint2(0u, 0u);
+	unsigned long long gpos = 0;
+	if (t0 < T) {
+		f4 = *reinterpret_cast<const unsigned *>(w.tok_flag + img * w.TS + t0);
+		o4 = *reinterpret_cast<const unsigned *>(w.tok_ord + img * w.TS + t0);
+		r4 = *reinterpret_cast<const uint4 *>(w.tok_run + img * w.TS + t0);
+		off4 = *reinterpret_cast<const uint2 *>(w.tok_off + img * w.TS + t0);
+		const long left = T - t0;   // tokens past T are stale scratch
+		if (left < EMIT_TOK) {
+			const unsigned keep = left > 2 ? 0x00ffffffu : left > 1 ? 0x0000ffffu : 0x000000ffu;
+			f4 = (f4 & keep) | ((F_VOID * 0x01010101u) & ~keep);
+		}
+		const long group = t0 / SUB;
+		const long chunk = group / (w.slow[img] ? 64 : FSUBS);
+		gpos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[img * w.NCS * 64 + group];
 	}
-	unsigned long long code = 0;
-	int len = 0;
-	if (!(f & F_VOID)) {
-		const int o = w.tok_ord[img * w.TS + t];
-		const unsigned v = w.tok_run[img * w.TS + t];
-		const int top = vli_top(o, v);
-		const int z = top - o;
-		code = (1ull << z) | ((unsigned long long)(v + (1u << o) - (1u << top)) << (z + 1));
-		len = z + 1 + top;
-		if (f & F_HAS_SIGN) {
-			code |= (unsigned long long)(f & F_SIGN) << len;
-			++len;
+	const unsigned run[EMIT_TOK] = { r4.x, r4.y, r4.z, r4.w };
+	unsigned long long pos[EMIT_TOK], code[EMIT_TOK];
+	int len[EMIT_TOK];
+#pragma unroll
+	for (int e = 0; e < EMIT_TOK; ++e) {
+		const unsigned f = (f4 >> (8 * e)) & 255u;
+		pos[e] = gpos + (((e & 1) ? (e & 2 ? off4.y : off4.x) >> 16 : (e & 2 ? off4.y : off4.x)) & 0xffffu);
+		code[e] = 0;
+		len[e] = 0;
+		if (!(f & F_VOID)) {
+			const int o = (int)((o4 >> (8 * e)) & 255u);
+			const unsigned v = run[e];
+			const int top = vli_top(o, v);
+			const int z = top - o;
+			code[e] = (1ull << z) | ((unsigned long long)(v + (1u << o) - (1u << top)) << (z + 1));
+			len[e] = z + 1 + top;
+			if (f & F_HAS_SIGN) {
+				code[e] |= (unsigned long long)(f & F_SIGN) << len[e];
+				++len[e];
+			}
 		}
 	}
-	if (myseg >= 0)
-		w.seg_rawoff[(long)img * MAX_SEGS + myseg] = pos + (unsigned)len;
-	// The 64 tokens of a group are adjacent in the stream (a few bits each): merge them in an LDS
-	// window of COMB words first, so each stream word costs one global atomic per wave.  Tokens
-	// pushed far away by a refinement block go to memory directly.
+	// break tokens are followed by their segment's refinement block: later tokens of the same 64-token
+	// group move up by its size (k_orders_fast / k_orders counted it for the groups after that)
+	const unsigned brk4 = f4 & (F_BREAK * 0x01010101u);
+	bool split = false;   // a refinement block lies between this lane's tokens
+	if (__ballot(brk4 != 0)) {
+#pragma unroll
+		for (int e = 0; e < EMIT_TOK; ++e) {
+			unsigned long long bm = __ballot((brk4 >> (8 * e)) & F_BREAK);
+			while (bm) {
+				const int j = __builtin_ctzll(bm);
+				bm &= bm - 1;
+				const long tb = wave * (64 * EMIT_TOK) + j * EMIT_TOK + e;   // the break token
+				const long k = find_break_seg(btok, I.K, (unsigned)tb);
+				const unsigned refs = srefs[k];
+#pragma unroll
+				for (int q = 0; q < EMIT_TOK; ++q) {
+					const long tq = t0 + q;
+					if (tq > tb && tq / SUB == tb / SUB) {
+						pos[q] += refs;
+						split = split || (refs != 0 && lane == j);
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EMIT_TOK; ++e)   // every shift is in: where each break's refinement block starts
+			if ((brk4 >> (8 * e)) & F_BREAK)
+				w.seg_rawoff[(long)img * MAX_SEGS + find_break_seg(btok, I.K, (unsigned)(t0 + e))] = pos[e] + (unsigned)len[e];
+	}
 	unsigned *cw = comb[threadIdx.x >> 6];
 	for (int i = lane; i < COMB; i += 64)
 		cw[i] = 0;
-	const long wbase = (long)(__shfl(pos, 0) >> 5);
+	const long wbase = (long)(__shfl(pos[0], 0) >> 5);
 	__builtin_amdgcn_wave_barrier();
 	unsigned *dst = out + img * out_words;
-	if (len) {
-		const long w0 = (long)(pos >> 5);
-		const int sh = (int)(pos & 31);
-		const unsigned long long lo = code << sh;
-		const unsigned part[3] = { (unsigned)lo, (unsigned)(lo >> 32), sh ? (unsigned)(code >> (64 - sh)) : 0u };
+	auto put = [&](unsigned long long p, unsigned long long c) {   // up to 64 code bits at bit position p
+		const long w0 = (long)(p >> 5);
+		const int sh = (int)(p & 31);
+		const unsigned long long lo = c << sh;
+		const unsigned part[3] = { (unsigned)lo, (unsigned)(lo >> 32), sh ? (unsigned)(c >> (64 - sh)) : 0u };
 #pragma unroll
 		for (int q = 0; q < 3; ++q) {
 			const long wi = w0 + q;
@@ -1168,6 +1204,24 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 			else if (wi < out_words)
 				atomicOr(dst + wi, part[q]);
 		}
+	};
+	const int total = len[0] + len[1] + len[2] + len[3];
+	// tokens of one 64-token group follow each other bit for bit (a lane never straddles two groups)
+	if (!split && total <= 64) {
+		unsigned long long c = 0;
+		int at = 0;
+#pragma unroll
+		for (int e = 0; e < EMIT_TOK; ++e) {
+			c |= len[e] ? code[e] << at : 0ull;
+			at += len[e];
+		}
+		if (total)
+			put(pos[0], c);
+	} else {
+#pragma unroll
+		for (int e = 0; e < EMIT_TOK; ++e)
+			if (len[e])
+				put(pos[e], code[e]);
 	}
 	__builtin_amdgcn_wave_barrier();
 	for (int i = lane; i < COMB; i += 64) {
@@ -1461,7 +1515,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
 	hipLaunchKernelGGL(k_orders, dim3(512, n), dim3(64 * ORD_WAVES), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
-	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.NCS * 64 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / (64 * EMIT_TOK) + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
