@@ -760,6 +760,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	bm.cur = -1;
 	bm.acc = 0;
 	bm.lead = threadIdx.x == 0;
+	const int wl = (int)threadIdx.x;   // lane, for the few places where the lanes share work
 
 	unsigned cnt = 0;              // rle.h:25
 	unsigned long long symtotal = 0;
@@ -831,13 +832,16 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							if (hi >= ci && CS[hi + 1] - s0 <= (unsigned long long)need) {
 								lo = hi;
 							} else {
+								// 64-way search: lane j probes lo + (j+1)*stride; the predicate is true up to the answer
 								hi = hi - 1;
 								while (lo < hi) {
-									const long mid = (lo + hi + 1) >> 1;
-									if (CS[mid + 1] - s0 <= (unsigned long long)need)
-										lo = mid;
-									else
-										hi = mid - 1;
+									const long span = hi - lo, stride = (span + 63) >> 6;
+									const long step = (long)(wl + 1) * stride;
+									const long probe = lo + (step < span ? step : span);
+									const int t = __builtin_popcountll(__ballot(CS[probe + 1] - s0 <= (unsigned long long)need));
+									const long reach = (long)t * stride, next = (long)(t + 1) * stride;
+									hi = t == 64 ? hi : lo + (next < span ? next : span) - 1;
+									lo = lo + (reach < span ? reach : span);
 								}
 							}
 							if (lo >= ci) {
