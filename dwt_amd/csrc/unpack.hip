@@ -100,6 +100,7 @@ struct DWork {
 	long todo_cap;
 	unsigned long long *dbg;
 	int *nhops;                     // [n]
+	int *nch;                       // [n] chunks that hold stream bytes (rounded so that nch+1 is a multiple of 4), <= NCH
 	long NCH, NB;
 	long MAX_HOPS;
 };
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y, img = vs / FAM;   // virtual stream = (image, family)
-	if (chunk >= w.NCH)
+	if (chunk >= w.nch[img])
 		return;
 	const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
 	// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
@@ -390,7 +391,7 @@ __device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *
 	w.cs[ci] = sym;
 	w.ct[ci] = tok;
 	w.exitX[vs * w.NCH + ch] = out;
-	return out != old && ch + 1 < w.NCH;
+	return out != old && ch + 1 < w.nch[img];
 }
 
 // queue chunk `ch` for the next round; one atomic per (wave, shard) instead of one per lane.
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
 	bool moved = false;
-	if (chunk >= 1 && chunk < w.NCH)
+	if (chunk >= 1 && chunk < w.nch[vs / FAM])
 		moved = link_parse(w, streams, stream_stride, vs, chunk);
 	link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count[1]);
 }
@@ -450,10 +451,11 @@ __global__ __launch_bounds__(256) void k_link_final(DWork w)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
-	if (chunk > w.NCH)
+	const long nch = w.nch[vs / FAM];
+	if (chunk > nch)
 		return;
 	const long ci = vs * (w.NCH + 1) + chunk;
-	if (chunk == 0 || chunk == w.NCH) {   // chunk 0 has no predecessor; element NCH is the scan sentinel
+	if (chunk == 0 || chunk == nch) {   // chunk 0 has no predecessor; element nch is the scan sentinel
 		w.cs[ci] = 0;
 		w.ct[ci] = 0;
 		w.cg[ci] = chunk == 0 ? 1u : 0u;
@@ -514,54 +516,87 @@ __device__ __forceinline__ Tri block_scan_tri(Tri v, Tri *wsum, Tri &total)
 	return ex;
 }
 
+// Four consecutive elements per thread (NCH+1 is a multiple of 4: whole vectors are in or out)
+struct Quad {
+	ulonglong2 s01, s23;
+	uint4 t, g;
+};
+
+__device__ __forceinline__ Quad quad_load(const DWork &w, long at)
+{
+	Quad q;
+	q.s01 = *reinterpret_cast<const ulonglong2 *>(w.cs + at);
+	q.s23 = *reinterpret_cast<const ulonglong2 *>(w.cs + at + 2);
+	q.t = *reinterpret_cast<const uint4 *>(w.ct + at);
+	q.g = *reinterpret_cast<const uint4 *>(w.cg + at);
+	return q;
+}
+
+__device__ __forceinline__ void quad_store(const DWork &w, long at, const Quad &q)
+{
+	*reinterpret_cast<ulonglong2 *>(w.cs + at) = q.s01;
+	*reinterpret_cast<ulonglong2 *>(w.cs + at + 2) = q.s23;
+	*reinterpret_cast<uint4 *>(w.ct + at) = q.t;
+	*reinterpret_cast<uint4 *>(w.cg + at) = q.g;
+}
+
 __global__ __launch_bounds__(256) void k_scan_local(DWork w)
 {
 	__shared__ Tri wsum[4];
-	const int img = blockIdx.y;
-	const long n = w.NCH + 1;
-	unsigned long long *cs = w.cs + img * n;
-	unsigned *ct = w.ct + img * n, *cg = w.cg + img * n;
-	Tri carry = { 0, 0, 0 };
-	for (int q = 0; q < SCAN_BLOCK / 256; ++q) {   // lane-contiguous rows of 256 elements
-		const long i = (long)blockIdx.x * SCAN_BLOCK + q * 256 + threadIdx.x;
-		Tri v = { 0, 0, 0 };
-		if (i < n) {
-			v.s = cs[i];
-			v.t = ct[i];
-			v.g = cg[i];
-		}
-		Tri total;
-		const Tri pre = block_scan_tri(v, wsum, total);
-		if (i < n) {
-			cs[i] = carry.s + pre.s;
-			ct[i] = carry.t + pre.t;
-			cg[i] = carry.g + pre.g;
-		}
-		carry = tri_add(carry, total);
+	const int img = blockIdx.y;   // virtual stream
+	const long n = w.NCH + 1, used = w.nch[img / FAM] + 1;
+	if ((long)blockIdx.x * SCAN_BLOCK >= used)
+		return;
+	const long i = (long)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
+	const bool in = i < used;
+	Quad q;
+	q.s01 = q.s23 = make_ulonglong2(0ull, 0ull);
+	q.t = q.g = make_uint4(0u, 0u, 0u, 0u);
+	if (in)
+		q = quad_load(w, img * n + i);
+	const Tri mine = { q.s01.x + q.s01.y + q.s23.x + q.s23.y, q.t.x + q.t.y + q.t.z + q.t.w, q.g.x + q.g.y + q.g.z + q.g.w };
+	Tri total;
+	const Tri pre = block_scan_tri(mine, wsum, total);
+	if (in) {
+		Quad o;
+		o.s01.x = pre.s;
+		o.s01.y = o.s01.x + q.s01.x;
+		o.s23.x = o.s01.y + q.s01.y;
+		o.s23.y = o.s23.x + q.s23.x;
+		o.t.x = pre.t;
+		o.t.y = o.t.x + q.t.x;
+		o.t.z = o.t.y + q.t.y;
+		o.t.w = o.t.z + q.t.z;
+		o.g.x = pre.g;
+		o.g.y = o.g.x + q.g.x;
+		o.g.z = o.g.y + q.g.y;
+		o.g.w = o.g.z + q.g.z;
+		quad_store(w, img * n + i, o);
 	}
 	if (threadIdx.x == 0) {
-		w.part_s[img * w.NB + blockIdx.x] = carry.s;
-		w.part_t[img * w.NB + blockIdx.x] = carry.t;
-		w.part_g[img * w.NB + blockIdx.x] = carry.g;
+		w.part_s[img * w.NB + blockIdx.x] = total.s;
+		w.part_t[img * w.NB + blockIdx.x] = total.t;
+		w.part_g[img * w.NB + blockIdx.x] = total.g;
 	}
 }
 
 __global__ __launch_bounds__(256) void k_scan_parts(DWork w)
 {
 	__shared__ Tri wsum[4];
-	const int img = blockIdx.x;
+	const int img = blockIdx.x;   // virtual stream
+	const long nb = (w.nch[img / FAM] + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;   // blocks k_scan_local ran
 	Tri carry = { 0, 0, 0 };
-	for (long b0 = 0; b0 < w.NB; b0 += 256) {
+	for (long b0 = 0; b0 < nb; b0 += 256) {
 		const long i = b0 + threadIdx.x;
 		Tri v = { 0, 0, 0 };
-		if (i < w.NB) {
+		if (i < nb) {
 			v.s = w.part_s[img * w.NB + i];
 			v.t = w.part_t[img * w.NB + i];
 			v.g = w.part_g[img * w.NB + i];
 		}
 		Tri total;
 		const Tri pre = block_scan_tri(v, wsum, total);
-		if (i < w.NB) {
+		if (i < nb) {
 			w.part_s[img * w.NB + i] = carry.s + pre.s;
 			w.part_t[img * w.NB + i] = carry.t + pre.t;
 			w.part_g[img * w.NB + i] = carry.g + pre.g;
@@ -572,18 +607,27 @@ __global__ __launch_bounds__(256) void k_scan_parts(DWork w)
 
 __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 {
-	const int img = blockIdx.y;
+	const int img = blockIdx.y;   // virtual stream
 	const long n = w.NCH + 1;
+	const long i = (long)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
+	if (i >= w.nch[img / FAM] + 1 || blockIdx.x == 0)   // the first block's prefixes are final already
+		return;
 	const unsigned long long ps = w.part_s[img * w.NB + blockIdx.x];
 	const unsigned pt = w.part_t[img * w.NB + blockIdx.x], pg = w.part_g[img * w.NB + blockIdx.x];
-	for (int q = 0; q < SCAN_BLOCK / 256; ++q) {
-		const long i = (long)blockIdx.x * SCAN_BLOCK + q * 256 + threadIdx.x;
-		if (i < n) {
-			w.cs[img * n + i] += ps;
-			w.ct[img * n + i] += pt;
-			w.cg[img * n + i] += pg;
-		}
-	}
+	Quad q = quad_load(w, img * n + i);
+	q.s01.x += ps;
+	q.s01.y += ps;
+	q.s23.x += ps;
+	q.s23.y += ps;
+	q.t.x += pt;
+	q.t.y += pt;
+	q.t.z += pt;
+	q.t.w += pt;
+	q.g.x += pg;
+	q.g.y += pg;
+	q.g.z += pg;
+	q.g.w += pg;
+	quad_store(w, img * n + i, q);
 }
 
 // compact list of the unjoined chunks: the one with rank r (= cg[i], exclusive prefix) goes to slot r
@@ -591,7 +635,7 @@ __global__ __launch_bounds__(256) void k_breaks(DWork w)
 {
 	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
-	if (chunk >= w.NCH)
+	if (chunk >= w.nch[vs / FAM])
 		return;
 	const unsigned *cg = w.cg + (long)vs * (w.NCH + 1);
 	if (cg[chunk + 1] != cg[chunk])
@@ -616,7 +660,7 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		else
 			hi = mid;
 	}
-	if (chunk >= w.NCH || chunk < 1)
+	if (chunk >= w.nch[img] || chunk < 1)
 		return;
 	int h = lo;
 	while (h < nh && hl[h] < (unsigned)chunk)
@@ -822,7 +866,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							// that still fits.
 							const unsigned long long *CS = CS0 + fam * (w.NCH + 1);
 							const unsigned *CT = CT0 + fam * (w.NCH + 1), *CG = CG0 + fam * (w.NCH + 1);
-							const unsigned g0 = CG[ci], g1 = CG[ci + 1], gtot = CG[w.NCH];
+							const unsigned g0 = CG[ci], g1 = CG[ci + 1], gtot = CG[w.nch[img]];
 							if (g1 != g0)
 								continue;   // chunk ci itself was recorded from another entry state
 							const unsigned long long s0 = CS[ci];
@@ -1190,6 +1234,19 @@ __global__ __launch_bounds__(256) void k_tiles_init(UnpackGeom g, DWork w, int n
 	w.tile_nonsig[(long)plane * w.NT + tile] = (unsigned short)(left < TILE ? left : TILE);
 }
 
+// The chunk tables are laid out for the stream stride, but only the chunks that hold stream bytes are
+// worked on: nch[i] (+1 sentinel row) is a multiple of 4 like NCH + 1, for the vectorised scans.
+__global__ __launch_bounds__(256) void k_nch(DWork w, const unsigned long long *lens, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const unsigned long long bits = lens[i] * 8ull;
+	long c = (long)((bits + CH_BITS - 1) / CH_BITS);
+	c = (c + 1 + 3) / 4 * 4 - 1;
+	w.nch[i] = (int)(c < w.NCH ? c : w.NCH);
+}
+
 } // namespace
 
 enum { SLOT_UP_SMALL = 12, SLOT_UP_BITS, SLOT_UP_TILES, SLOT_UP_CHUNKS };
@@ -1265,6 +1322,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		w.tile_rank = (unsigned *)(tiles + o_tr);
 		// speculative chunk tables
 		w.NCH = (long)((stream_stride * 8 + CH_BITS - 1) / CH_BITS);
+		w.NCH = (w.NCH + 1 + 3) / 4 * 4 - 1;   // NCH+1 table rows per stream, a multiple of 4 for the vectorised scans
 		w.NB = (w.NCH + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
 		off = 0;
 		w.MAX_HOPS = 8 * MAX_SEGS + w.NCH / 8;
@@ -1287,6 +1345,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		const size_t o_td = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64 * w.todo_cap);
 		const size_t o_tc = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64);
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
+		const size_t o_nc = take(sizeof(int) * (size_t)n);
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
 		if (!chunks)
 			return DWTX_ERR_NOMEM;
@@ -1310,6 +1369,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		w.todo_count[0] = (unsigned *)(chunks + o_tc);
 		w.todo_count[1] = w.todo_count[0] + (size_t)n * FAM * 64;
 		w.nhops = (int *)(chunks + o_nh);
+		w.nch = (int *)(chunks + o_nc);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)n * w.BW, ctx->stream));
@@ -1319,6 +1379,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	// the root image (written by the token walker when it has any bits) needs clearing
 	DWTX_HIP(hipMemset2DAsync(lin, sizeof(int) * (size_t)g.lin_stride, 0, sizeof(int) * (size_t)g.pixels[0], nplanes, s));
 	hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, nplanes);
+	hipLaunchKernelGGL(k_nch, dim3(dwtx_cdiv(n, 256)), dim3(256), 0, s, w, dev_lens, n);
 
 	// everything below works on a range of images [i0, i0+cnt): all tables are per image
 	auto slice = [&](int i0) {
@@ -1353,6 +1414,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 			h.todo_count[k] += (size_t)i0 * FAM * 64;
 		}
 		h.nhops += i0;
+		h.nch += i0;
 		if (h.dbg)
 			h.dbg += (size_t)i0 * 4;
 		return h;
