@@ -1104,40 +1104,51 @@ __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 	}
 }
 
-// ones among the tile's symbols at plane p = popcount of its slice of the bitmap
+// ones among the tile's symbols at plane p = popcount of its slice of the bitmap; 16 lanes share a
+// tile (a slice is at most 64 words).  Bit 31 of the tile's rank entry records "this plane turns
+// coefficients of this tile on" for k_apply_all.
+constexpr int COUNT_LANES = 16;
+
 __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 {
-	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+	const int sub = threadIdx.x & (COUNT_LANES - 1);
+	const int tile = (blockIdx.x * blockDim.x + threadIdx.x) / COUNT_LANES;
 	const int plane = blockIdx.y;
-	if (tile >= w.NT)
-		return;
 	const int img = plane / g.C, c = plane - img * g.C;
-	if (w.info[img].status)
-		return;
-	int l = 0;
-	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
-		++l;
-	const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
-	if (!k1)
-		return;
-	unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + tile;
-	const unsigned n = *ns;
-	if (!n)
-		return;
-	const unsigned *sym = w.symbits + img * w.BW;
-	const unsigned long long a = 2 * (w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] +
-		w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile]);
-	const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
-	unsigned ones = 0;
-	for (unsigned long long wi = a >> 5; wi <= (e - 1) >> 5; ++wi) {
-		unsigned m = sym[wi] & 0x55555555u;
-		if (wi == a >> 5)
-			m &= ~0u << (a & 31);
-		if (wi == (e - 1) >> 5 && (e & 31))
-			m &= (1u << (e & 31)) - 1u;
-		ones += (unsigned)__builtin_popcount(m);
+	bool live = tile < w.NT && !w.info[img].status;
+	int k1 = 0;
+	if (live) {
+		int l = 0;
+		while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+			++l;
+		k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
+		live = k1 != 0;
 	}
-	*ns = (unsigned short)(n - ones);
+	unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + tile;
+	const unsigned n = live ? *ns : 0u;
+	live = live && n != 0;
+	unsigned ones = 0;
+	unsigned *rk = w.tile_rank + ((long)plane * MAX_PLANES + p) * w.NT + tile;
+	if (live) {
+		const unsigned *sym = w.symbits + img * w.BW;
+		const unsigned long long a = 2 * (w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] + *rk);
+		const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
+		const unsigned long long first = a >> 5, last = (e - 1) >> 5;
+		for (unsigned long long wi = first + sub; wi <= last; wi += COUNT_LANES) {
+			unsigned m = sym[wi] & 0x55555555u;
+			if (wi == first)
+				m &= ~0u << (a & 31);
+			if (wi == last && (e & 31))
+				m &= (1u << (e & 31)) - 1u;
+			ones += (unsigned)__builtin_popcount(m);
+		}
+	}
+	for (int o = COUNT_LANES / 2; o; o >>= 1)
+		ones += __shfl_xor(ones, o);
+	if (live && sub == 0 && ones) {
+		*ns = (unsigned short)(n - ones);
+		*rk |= 0x80000000u;
+	}
 }
 
 // --------------------------------------------------------------- k_apply_all ---
@@ -1171,6 +1182,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	const unsigned idx0 = (unsigned)j * TILE + (unsigned)lane;                  // ring index of this lane's row-0 coefficient
 	unsigned mag[ROWS];
 	unsigned neg = 0;   // bit r: the coefficient of row r is negative
+	bool anysig = false;   // uniform: some coefficient of the tile is significant
 #pragma unroll
 	for (int r = 0; r < ROWS; ++r)
 		mag[r] = 0;
@@ -1181,7 +1193,13 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 		const int k = k1 - 1;
 		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
 		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
-		unsigned rank = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
+		const unsigned tr = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
+		// nothing to do while the tile is all zeros and this plane adds no ones to it (k_count's flag):
+		// on fine levels that is every plane above the noise floor
+		if (!(tr >> 31) && !anysig)
+			continue;
+		anysig = true;
+		unsigned rank = tr & 0x7fffffffu;
 		// Both sources are read as one 32-bit word per coefficient and plane: the symbol bitmap (two bits
 		// per symbol; a segment's symbols start on a word boundary) while the coefficient is
 		// insignificant, the stream's refinement block once it is significant.  The address is the
@@ -1463,7 +1481,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 				pmax = host_info[i].pmax;
 		for (int p = pmax - 1; p >= 0; --p) {
 			hipLaunchKernelGGL(k_rank, dim3(g.levels, cnt * C), dim3(1024), 0, st, g, h, p);
-			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT, 256), cnt * C), dim3(256), 0, st, g, h, p);
+			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT * COUNT_LANES, 256), cnt * C), dim3(256), 0, st, g, h, p);
 		}
 		hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), cnt * C), dim3(256), 0, st, g, h,
 			streams + (size_t)i0 * stream_stride, (long)stream_stride, lin + (size_t)i0 * C * g.lin_stride);
