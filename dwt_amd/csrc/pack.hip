@@ -498,6 +498,11 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 		if (!k1)
 			continue;
 		const int e = eb[k1 - 1] + j;
+		if (!w.ent_ones[img * w.ES + e]) {   // no token from this tile at this plane: its zeros just pass through
+			if (lane == 0)
+				w.ent_tz[img * w.ES + e] = w.ent_zeros[img * w.ES + e];
+			continue;
+		}
 		unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
 		unsigned pending = 0;   // zeros since the last one of this tile (uniform)
 #pragma unroll
