@@ -135,6 +135,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level(LevelArgs a)
 // 1..62 produce output (62 pairs = 124 columns per wave).
 
 constexpr int INV_PAIRS = 62;
+// wide inverse: 56 quads of output per wave = 896 bytes per row = seven whole 128-byte lines, so the
+// row stores of neighbouring waves never share a line (lanes 0 and 57 are the halo, 58-63 idle)
+constexpr int INV_QUADS = 56;
 
 struct InvLane {
 	int k;
@@ -460,14 +463,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int qd = blockIdx.x * INV_PAIRS - 1 + lane;
+	const int qd = blockIdx.x * INV_QUADS - 1 + lane;
 	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	const bool valid = qd >= 0 && qd < A.nquads;
-	const bool writes = valid && lane >= 1 && lane <= INV_PAIRS;
+	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
 	const int *llp = a.src + plane * a.src_ps;
 	const int *det = a.det + plane * a.det_ps;
 	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
@@ -1034,7 +1037,7 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, co
 		if (wide) {
 			LevelArgsW A;
 			A.nquads = a.w / 4;
-			const int sx = dwtx_cdiv(A.nquads, INV_PAIRS);
+			const int sx = dwtx_cdiv(A.nquads, INV_QUADS);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
