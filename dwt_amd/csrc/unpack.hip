@@ -96,7 +96,8 @@ struct DWork {
 	unsigned *hop_ntok;             // [n][MAX_HOPS] tokens to apply (walker-parsed chunk pieces)
 	unsigned *breaks;               // [n*FAM][NCH] chunk indices whose arriving path does not rejoin, ascending
 	unsigned *todo[2];              // [n*FAM][LINK_SHARDS][todo_cap] chunks to re-parse, this round / next round
-	unsigned *todo_count[2];        // [n*FAM][LINK_SHARDS]
+	unsigned *todo_count;           // [LINK_ROUNDS + 1][n*FAM][LINK_SHARDS]: entries queued for round r, zeroed once per call
+	long todo_round;                // elements per round of todo_count
 	long todo_cap;
 	unsigned long long *dbg;
 	int *nhops;                     // [n]
@@ -424,15 +425,15 @@ __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *
 	bool moved = false;
 	if (chunk >= 1 && chunk < w.nch[vs / FAM])
 		moved = link_parse(w, streams, stream_stride, vs, chunk);
-	link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count[1]);
+	link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count + 2 * w.todo_round);
 }
 
 // later rounds: the chunks queued by the previous one
-__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur)
+__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
 {
 	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
 		parts = gridDim.x / LINK_SHARDS;
-	const unsigned count = w.todo_count[cur][vs * LINK_SHARDS + shard];
+	const unsigned count = w.todo_count[round * w.todo_round + vs * LINK_SHARDS + shard];
 	const unsigned *list = w.todo[cur] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
 	for (unsigned q0 = part * blockDim.x; q0 < count; q0 += parts * blockDim.x) {   // uniform trip count per wave
 		const unsigned q = q0 + threadIdx.x;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char 
 			ch = list[q];
 			moved = link_parse(w, streams, stream_stride, vs, ch);
 		}
-		link_push(w, vs, ch + 1, moved, w.todo[cur ^ 1], w.todo_count[cur ^ 1]);
+		link_push(w, vs, ch + 1, moved, w.todo[cur ^ 1], w.todo_count + (round + 1) * w.todo_round);
 	}
 }
 
@@ -1361,7 +1362,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		const size_t o_br = take(sizeof(unsigned) * (size_t)n * FAM * w.NCH);
 		w.todo_cap = ((w.NCH + 256) / 256 + 63) / 64 * 256 + 256;   // chunks whose workgroup maps to one shard
 		const size_t o_td = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64 * w.todo_cap);
-		const size_t o_tc = take(sizeof(unsigned) * 2 * (size_t)n * FAM * 64);
+		const size_t o_tc = take(sizeof(unsigned) * (LINK_ROUNDS + 2) * (size_t)n * FAM * LINK_SHARDS);
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
 		const size_t o_nc = take(sizeof(int) * (size_t)n);
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
@@ -1384,8 +1385,9 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		w.breaks = (unsigned *)(chunks + o_br);
 		w.todo[0] = (unsigned *)(chunks + o_td);
 		w.todo[1] = w.todo[0] + (size_t)n * FAM * 64 * w.todo_cap;
-		w.todo_count[0] = (unsigned *)(chunks + o_tc);
-		w.todo_count[1] = w.todo_count[0] + (size_t)n * FAM * 64;
+		w.todo_count = (unsigned *)(chunks + o_tc);
+		w.todo_round = (long)n * FAM * LINK_SHARDS;
+		DWTX_HIP(hipMemsetAsync(w.todo_count, 0, sizeof(unsigned) * (LINK_ROUNDS + 2) * (size_t)w.todo_round, ctx->stream));
 		w.nhops = (int *)(chunks + o_nh);
 		w.nch = (int *)(chunks + o_nc);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
@@ -1427,10 +1429,9 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		h.hop_entry += (size_t)i0 * w.MAX_HOPS;
 		h.hop_ntok += (size_t)i0 * w.MAX_HOPS;
 		h.breaks += (size_t)i0 * FAM * w.NCH;
-		for (int k = 0; k < 2; ++k) {
+		for (int k = 0; k < 2; ++k)
 			h.todo[k] += (size_t)i0 * FAM * 64 * w.todo_cap;
-			h.todo_count[k] += (size_t)i0 * FAM * 64;
-		}
+		h.todo_count += (size_t)i0 * FAM * LINK_SHARDS;
 		h.nhops += i0;
 		h.nch += i0;
 		if (h.dbg)
@@ -1442,14 +1443,11 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		const DWork h = slice(i0);
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), cnt * FAM);
-		const size_t cnt_bytes = sizeof(unsigned) * (size_t)cnt * FAM * LINK_SHARDS;
 		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
-		DWTX_HIP(hipMemsetAsync(h.todo_count[1], 0, cnt_bytes, st));
-		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // fills list 1
+		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills list 1 for round 2
 		int cur = 1;
 		for (int r = 2; r <= LINK_ROUNDS; ++r) {
-			DWTX_HIP(hipMemsetAsync(h.todo_count[cur ^ 1], 0, cnt_bytes, st));
-			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur);
+			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
 			cur ^= 1;
 		}
 		hipLaunchKernelGGL(k_link_final, cg, dim3(256), 0, st, h);
