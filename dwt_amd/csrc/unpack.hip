@@ -42,7 +42,7 @@ constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
 constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
 constexpr int CH_BITS = 1 << CH_LOG2;
 constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
-constexpr int LINK_ROUNDS = 16;         // chunks of look-back behind every stitched entry state
+constexpr int LINK_ROUNDS = 12;         // relaxation rounds: fewer leave more chunks unstitched, more let paths that ran through refinement blocks take over (both cost the walker; measured optimum 10-12)
 constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
 
 struct UnpackGeom {
