@@ -661,20 +661,16 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		else
 			hi = mid;
 	}
-	if (chunk >= w.nch[img] || chunk < 1)
-		return;
-	int h = lo;
-	while (h < nh && hl[h] < (unsigned)chunk)
-		++h;
 	unsigned *sym = w.symbits + img * w.BW;
 	const long n = w.NCH + 1;
 	ChunkWin c;
 	bool loaded = false;
-	for (; h < nh && hf[h] <= (unsigned)chunk; ++h) {
+	// the tokens record h accounts for in this thread's chunk
+	auto piece = [&](int h) {
 		const int hs = w.hop_seg[(long)img * w.MAX_HOPS + h];
 		const int k = hs & 0xffff, vs = img * FAM + (hs >> 16);
 		if ((w.seg_desc[(long)img * MAX_SEGS + k] >> 8) == 0)
-			continue;   // plane -1 (flat image): symbols carry no bits
+			return;   // plane -1 (flat image): symbols carry no bits
 		if (!loaded) {
 			c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
 			loaded = true;
@@ -721,7 +717,22 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		});
 		if (acc)
 			atomicOr(sym + cur, acc);
+	};
+	const bool mine = chunk < w.nch[img] && chunk >= 1;
+	// Most workgroups lie inside one long hop: its record is then the same for every thread and is
+	// fetched through the scalar unit; only the chunk's own table rows are per-thread loads.
+	if (lo < nh && hf[lo] <= first_chunk && hl[lo] >= first_chunk + blockDim.x - 1 && (lo + 1 >= nh || hf[lo + 1] > first_chunk + blockDim.x - 1)) {
+		if (mine)
+			piece(lo);
+		return;
 	}
+	if (!mine)
+		return;
+	int h = lo;
+	while (h < nh && hl[h] < (unsigned)chunk)
+		++h;
+	for (; h < nh && hf[h] <= (unsigned)chunk; ++h)
+		piece(h);
 }
 
 // --------------------------------------------------------------- k_tokenize ---
