@@ -154,8 +154,8 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 	const bool full = total == npts;
 	const int w0 = g.widths[l], h0 = g.heights[l], w1 = g.widths[l + 1], h1 = g.heights[l + 1];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int slot[PTS];
-	long offs[PTS];
+	int slot[PTS], lidx[PTS];
+	long offs[PTS], sq = 0;
 	bool ok[PTS];
 	int running = 0;
 #pragma unroll
@@ -168,6 +168,8 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 			ok[q] = x < w1 && y < h1 && (x >= w0 || y >= h0);
 		}
 		offs[q] = (long)y * ppitch + x;
+		lidx[q] = (y & 31) * 33 + (x & 31);
+		sq = (long)(y & ~31) * ppitch + (x & ~31);
 		if (full) {
 			slot[q] = i;
 		} else {
@@ -189,6 +191,48 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 	}
 	const int first = blockIdx.y * PLANES_PER_GROUP;
 	const int last = min(first + PLANES_PER_GROUP, nplanes);
+	if (full && pl2 == 2 * BLK_LOG2) {
+		// A whole 32x32 square: stage it in LDS so that the pyramid side moves in full 128-byte rows
+		// (two per wave instruction) instead of 8x8 patches of 32-byte pieces; two tiles alternate so
+		// that one barrier per plane suffices.
+		__shared__ int tile[2][32 * 33];
+		for (int plane = first; plane < last; ++plane) {
+			int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
+			int *pp = pyr + plane * pyr_ps + sq;
+			int *t = tile[(plane - first) & 1];
+			if (INVERSE) {
+				int bias = 0;
+				if (missing) {
+					const int m = missing[(plane / C) * 48 + (plane % C) * 16 + l] - 2;
+					bias = m >= 0 ? 1 << m : 0;
+				}
+#pragma unroll
+				for (int q = 0; q < PTS; ++q) {
+					int v = lp[q * THREADS + threadIdx.x];
+					if (bias && v)
+						v += v < 0 ? -bias : bias;
+					t[lidx[q]] = v;
+				}
+				__syncthreads();
+#pragma unroll
+				for (int q = 0; q < PTS; ++q) {
+					const int i = q * THREADS + threadIdx.x, r = i >> 5, cx = i & 31;
+					pp[(long)r * ppitch + cx] = t[r * 33 + cx];
+				}
+			} else {
+#pragma unroll
+				for (int q = 0; q < PTS; ++q) {
+					const int i = q * THREADS + threadIdx.x, r = i >> 5, cx = i & 31;
+					t[r * 33 + cx] = pp[(long)r * ppitch + cx];
+				}
+				__syncthreads();
+#pragma unroll
+				for (int q = 0; q < PTS; ++q)
+					lp[q * THREADS + threadIdx.x] = t[lidx[q]];
+			}
+		}
+		return;
+	}
 	for (int plane = first; plane < last; ++plane) {
 		int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
 		int *pp = pyr + plane * pyr_ps;
