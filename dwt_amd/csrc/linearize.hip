@@ -53,6 +53,80 @@ __device__ __forceinline__ void hilbert_d2xy(int n, unsigned d, int &xo, int &yo
 	yo = (int)y;
 }
 
+// The curve inside an aligned 32x32 square is the same for every square up to the flips and
+// swaps its position on the coarser levels imposes.  Table: the first five levels of the
+// recursion for the 1024 points of a square (x | y << 8); the remaining levels only see the
+// square's index, which is uniform per workgroup, and act on all of its points alike.
+struct HilbertLow {
+	unsigned short xy[1 << (2 * BLK_LOG2)];
+};
+
+constexpr HilbertLow make_hilbert_low()
+{
+	HilbertLow t{};
+	for (unsigned i = 0; i < (1u << (2 * BLK_LOG2)); ++i) {
+		unsigned x = 0, y = 0, d = i;
+		for (unsigned s = 1; s < (1u << BLK_LOG2); s <<= 1) {
+			const unsigned rx = (d >> 1) & 1u;
+			const unsigned ry = (d ^ rx) & 1u;
+			if (rx && !ry) {
+				x ^= s - 1;
+				y ^= s - 1;
+			}
+			if (!ry) {
+				const unsigned tmp = x;
+				x = y;
+				y = tmp;
+			}
+			x |= rx ? s : 0u;
+			y |= ry ? s : 0u;
+			d >>= 2;
+		}
+		t.xy[i] = (unsigned short)(x | (y << 8));
+	}
+	return t;
+}
+
+__device__ const HilbertLow HILBERT_LOW = make_hilbert_low();
+
+// What the levels above a 32x32 square do to its points is one swap and two XOR masks (OR-ing in a
+// level's bit is an XOR too, the bit is still clear): x = (sw ? yl : xl) ^ mx, y = (sw ? xl : yl) ^ my.
+struct SquareMap {
+	bool sw;
+	unsigned mx, my;
+};
+
+__device__ __forceinline__ SquareMap square_map(int n, unsigned sq)   // square index = curve index >> 10, n >= 32
+{
+	SquareMap m = { false, 0u, 0u };
+	for (unsigned s = 1u << BLK_LOG2; s < (unsigned)n; s <<= 1) {
+		const unsigned rx = (sq >> 1) & 1u;
+		const unsigned ry = (sq ^ rx) & 1u;
+		if (rx && !ry) {
+			m.mx ^= s - 1;
+			m.my ^= s - 1;
+		}
+		if (!ry) {
+			const unsigned t = m.mx;
+			m.mx = m.my;
+			m.my = t;
+			m.sw = !m.sw;
+		}
+		m.mx ^= rx ? s : 0u;
+		m.my ^= ry ? s : 0u;
+		sq >>= 2;
+	}
+	return m;
+}
+
+__device__ __forceinline__ void hilbert_in_square(const SquareMap &m, int i, int &xo, int &yo)
+{
+	const unsigned e = HILBERT_LOW.xy[i];
+	const unsigned xl = e & 255u, yl = e >> 8;
+	xo = (int)((m.sw ? yl : xl) ^ m.mx);
+	yo = (int)((m.sw ? xl : yl) ^ m.my);
+}
+
 __device__ __forceinline__ int overlap(int lo, int len, int bound)
 {
 	// |[lo, lo+len) ∩ [0, bound)|
@@ -154,6 +228,7 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 	const bool full = total == npts;
 	const int w0 = g.widths[l], h0 = g.heights[l], w1 = g.widths[l + 1], h1 = g.heights[l + 1];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const SquareMap smap = square_map(n, (unsigned)lb);   // uniform
 	int slot[PTS], lidx[PTS];
 	long offs[PTS], sq = 0;
 	bool ok[PTS];
@@ -164,7 +239,10 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 		int x = 0, y = 0;
 		ok[q] = false;
 		if (i < npts) {
-			hilbert_d2xy(n, ((unsigned)lb << pl2) + (unsigned)i, x, y);
+			if (pl2 == 2 * BLK_LOG2)
+				hilbert_in_square(smap, i, x, y);
+			else
+				hilbert_d2xy(n, ((unsigned)lb << pl2) + (unsigned)i, x, y);
 			ok[q] = x < w1 && y < h1 && (x >= w0 || y >= h0);
 		}
 		offs[q] = (long)y * ppitch + x;
