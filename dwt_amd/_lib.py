@@ -36,7 +36,7 @@ class DecodeInfo(C.Structure):
         ("status", C.c_int), ("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("levels", C.c_int),
         ("planes", C.c_int * 3), ("pmax", C.c_int), ("level", C.c_int), ("nsegs", C.c_int),
         ("truncated", C.c_int), ("missing", C.c_int * 48), ("bits_used", C.c_ulonglong),
-        ("hops", C.c_uint), ("hopped_chunks", C.c_uint), ("walked_tokens", C.c_uint), ("pad", C.c_uint),
+        ("hops", C.c_uint), ("hopped_chunks", C.c_uint), ("walked_tokens", C.c_uint), ("zeros_left", C.c_uint),
     ]
 
 
@@ -78,6 +78,7 @@ SYMBOLS = {
     "dwtx_decode_device": (_i, [_vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "dwtx_encode_images": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp, _vp]),
     "dwtx_decode_images": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "dwtx_decode_images_info": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "dwtx_decode_planes": (_i, [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _vp]),
     "dwtx_encode_planes": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_long, _vp, _sz, _vp]),
 }

@@ -50,7 +50,8 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	int ow, oh, oc;
-	int rc = dwtx_decode_images(ctx, padded, stride, &len, 1, pixels_max, pix, (size_t)W * H * C, &ow, &oh, &oc);
+	dwtx_decode_info info;
+	int rc = dwtx_decode_images_info(ctx, padded, stride, &len, 1, pixels_max, pix, (size_t)W * H * C, &ow, &oh, &oc, &info);
 	if (rc == DWTX_ERR_IO) {   /* decode.c:181,185: root image or plane counts cut off */
 		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);
 		return 1;
@@ -59,6 +60,10 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%s\n", dwtx_last_error());
 		return 1;
 	}
+	if (info.truncated & 2)    /* bytes.h:99-103: get_byte() ran into the end of a cut-off stream; decoding goes on with what it has */
+		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);
+	if (info.zeros_left > 1)   /* rle.h:43-46: the PIXELS cap (or the end of data) left part of a zero run unread */
+		fprintf(stderr, "%u zeros not read.\n", info.zeros_left);
 	if (!pnm_write(argv[2], pix, ow, oh, oc))
 		return 1;
 	dwtx_ctx_destroy(ctx);

@@ -188,6 +188,12 @@ extern "C" int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *pix, int W, int 
 extern "C" int dwtx_decode_images(dwtx_ctx *ctx, const uint8_t *streams, size_t stream_stride, const size_t *lens, int n,
 	int pixels_max, uint8_t *pix, size_t pix_stride, int *outW, int *outH, int *outC)
 {
+	return dwtx_decode_images_info(ctx, streams, stream_stride, lens, n, pixels_max, pix, pix_stride, outW, outH, outC, nullptr);
+}
+
+extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, size_t stream_stride, const size_t *lens, int n,
+	int pixels_max, uint8_t *pix, size_t pix_stride, int *outW, int *outH, int *outC, dwtx_decode_info *infos)
+{
 	if (!ctx || !streams || !lens || !pix || !outW || !outH || !outC || n < 1 || (stream_stride & 7))
 		return DWTX_ERR_ARG;
 	// decode.c:142-159: geometry comes from the first stream's header; all streams of a batch share it
@@ -239,6 +245,8 @@ extern "C" int dwtx_decode_images(dwtx_ctx *ctx, const uint8_t *streams, size_t 
 	}
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(ctx->stream);
+	if (infos && e == hipSuccess && (rc == DWTX_OK || rc == DWTX_ERR_IO))
+		memcpy(infos, info, sizeof(dwtx_decode_info) * (size_t)n);
 	free(hl);
 	free(info);
 	if (e != hipSuccess) {

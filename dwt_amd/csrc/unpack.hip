@@ -62,11 +62,12 @@ struct DecInfo {
 	int pmax;
 	int level;             // finest level any segment touched (decode.c:197,203,219,236); -1 none
 	int nsegs;
-	int truncated;         // a segment ended early (EOF) or the PIXELS cap stopped the walk
+	int truncated;         // bit 0: the walk stopped early; bit 1: because a read ran past the end of the data (bytes.h:99-103)
 	int missing[48];       // decode.c:193-196: planes not fully decoded, [c*16 + l]
 	unsigned long long bits_used;
 	unsigned hops, hopped_chunks;      // walker statistics: jumps over stitched chunks
-	unsigned walked_tokens, pad;       // tokens the walker had to parse itself
+	unsigned walked_tokens;            // tokens the walker had to parse itself
+	unsigned zeros_left;               // the run-length reader's counter at the end (rle.h:43-46 reports it when > 1)
 };
 
 struct DWork {
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	int nhops = 0;
 	unsigned hopped = 0, walked = 0;
 	bool br_synced = true;   // br's look-ahead registers match br.b
+	bool eof = false;        // a read ran past the end of the data (the reference prints bytes.h:101 once)
 	int *hop_seg = w.hop_seg + (long)img * w.MAX_HOPS;
 	unsigned *hop_first = w.hop_first + (long)img * w.MAX_HOPS, *hop_last = w.hop_last + (long)img * w.MAX_HOPS,
 		*hop_q0 = w.hop_q0 + (long)img * w.MAX_HOPS, *hop_entry = w.hop_entry + (long)img * w.MAX_HOPS,
@@ -955,6 +957,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 				unsigned v;
 				if (!br.vli(order, v)) {
 					ok = false;
+					eof = true;
 					break;
 				}
 				++walked;
@@ -981,6 +984,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			if (!br.read(1, neg)) {     // magnitude bit stays, sign unknown (decode.c:80-85)
 				++q;
 				ok = false;
+				eof = true;
 				break;
 			}
 			if (neg && p >= 0)
@@ -993,8 +997,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			return false;
 		if (p >= 0 && n2 > 0) {
 			if (cnt > 0) {              // rle.h:95-101: a pending run must end exactly here
-				if (cnt != 1)
+				if (cnt != 1) {
+					--cnt;   // get_rle() has taken one zero before rle_get_bit() gives up
 					return false;
+				}
 				cnt = 0;
 			}
 			sb2[k] = br.b;
@@ -1002,6 +1008,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			if ((unsigned long long)n2 > av) {
 				sn2[k] = (unsigned)av;
 				br.b = br.end_bits;
+				eof = true;
 				return false;
 			}
 			sn2[k] = (unsigned)n2;
@@ -1057,11 +1064,11 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.hops = (unsigned)nhops;
 	I.hopped_chunks = hopped;
 	I.walked_tokens = walked;
-	I.pad = 0;
+	I.zeros_left = cnt;
 	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; w.dbg[img * 4 + 3] = n_fast; }
 	I.level = level;
 	I.nsegs = nsegs;
-	I.truncated = stop ? 1 : 0;
+	I.truncated = stop ? (eof ? 3 : 1) : 0;
 	I.bits_used = br.b;
 }
 

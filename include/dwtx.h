@@ -87,11 +87,13 @@ typedef struct dwtx_decode_info {
 	int pmax;
 	int level;                     /* finest level any segment touched (decode.c:197,203,219,236); -1 = none */
 	int nsegs;
-	int truncated;                 /* the walk stopped early (end of data or PIXELS cap) */
+	int truncated;                 /* bit 0: the walk stopped early (end of data or PIXELS cap); bit 1: a read ran past
+	                                * the end of the data (where decode prints bytes.h:101 "reached end of file") */
 	int missing[48];               /* decode.c:193-196: planes not fully decoded, [channel*16 + level] */
 	unsigned long long bits_used;
 	unsigned hops, hopped_chunks;  /* token walker statistics: jumps over stitched 128-bit chunks */
-	unsigned walked_tokens, pad;   /* tokens the walker parsed itself */
+	unsigned walked_tokens;        /* tokens the walker parsed itself */
+	unsigned zeros_left;           /* run-length counter at the end; decode prints rle.h:45 "%d zeros not read." if > 1 */
 } dwtx_decode_info;
 
 /* ---- context / memory ---------------------------------------------------- */
@@ -195,6 +197,10 @@ int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *host_pix, int W, int H, int
 	uint8_t *host_out, size_t out_stride, size_t *out_lens, dwtx_stats *stats);
 int dwtx_decode_images(dwtx_ctx *ctx, const uint8_t *host_streams, size_t stream_stride, const size_t *lens, int n,
 	int pixels_max, uint8_t *host_pix, size_t pix_stride, int *outW, int *outH, int *outC);
+/* Same, and copies the n decoder records to `infos` (may be NULL): what decode.c needs for its
+ * stderr diagnostics (bytes.h:101, rle.h:45). */
+int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *host_streams, size_t stream_stride, const size_t *lens, int n,
+	int pixels_max, uint8_t *host_pix, size_t pix_stride, int *outW, int *outH, int *outC, dwtx_decode_info *infos);
 
 #ifdef __cplusplus
 }

@@ -90,3 +90,32 @@ def test_against_reference_binaries(tmp_path):
         assert run(os.path.join(orc.REF_DIR, "decode"), a, pa).returncode == 0
         assert run(DEC, a, pb).returncode == 0
         assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
+def _stderr_cases():
+    import json
+
+    recs = json.load(open(os.path.join(orc.GOLDEN, "decode_stderr.json")))
+    picked, seen = [], set()
+    for r in recs:
+        key = (r["fixture"], r["returncode"], r["stderr"], r["pixels_arg"] is None)
+        if "zeros not read" in r["stderr"] or key not in seen:
+            picked.append(r)
+        seen.add(key)
+    return picked
+
+
+@pytest.mark.parametrize("rec", _stderr_cases(), ids=lambda r: f"{r['fixture']}-{r['cut']}-{r['pixels_arg']}")
+def test_decode_diagnostics_match_the_reference(tmp_path, rec):
+    """decode's exit code and stderr text (bytes.h:101 "reached end of file", rle.h:45 "zeros not
+    read.") for whole, cut-off and PIXELS-capped streams, as recorded from the real reference
+    (tests/golden/make_decode_stderr.py)."""
+    data = open(os.path.join(orc.GOLDEN, rec["fixture"]), "rb").read()[: rec["cut"]]
+    (tmp_path / "in.dwt").write_bytes(data)
+    cmd = [DEC, "in.dwt", "out.pnm"] + ([str(rec["pixels_arg"])] if rec["pixels_arg"] is not None else [])
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, timeout=300)
+    assert r.returncode == rec["returncode"], r.stderr[-300:]
+    assert r.stderr.decode() == rec["stderr"]
+    if rec["returncode"] == 0:
+        want = orc.decode(data, -1 if rec["pixels_arg"] is None else rec["pixels_arg"])
+        assert (orc.read_pnm(str(tmp_path / "out.pnm")) == want).all()
