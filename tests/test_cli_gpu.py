@@ -119,3 +119,32 @@ def test_decode_diagnostics_match_the_reference(tmp_path, rec):
     if rec["returncode"] == 0:
         want = orc.decode(data, -1 if rec["pixels_arg"] is None else rec["pixels_arg"])
         assert (orc.read_pnm(str(tmp_path / "out.pnm")) == want).all()
+
+
+def _small_goldens():
+    import json
+
+    g = json.load(open(os.path.join(orc.GOLDEN, "golden.json")))
+    return sorted(k for k, v in g.items() if v["seed"] is not None and v["W"] * v["H"] <= 640 * 360)
+
+
+@pytest.mark.parametrize("name", _small_goldens())
+def test_encode_cli_against_reference_goldens(tmp_path, name):
+    """encode's three stderr lines (encode.c:176,180,230), its bytes and decode's picture for the
+    synthetic goldens the real reference produced (capacity and PIXELS arguments included)."""
+    import hashlib
+    import json
+
+    rec = json.load(open(os.path.join(orc.GOLDEN, "golden.json")))[name]
+    src, dwt, pnm = str(tmp_path / "in.pnm"), str(tmp_path / "o.dwt"), str(tmp_path / "o.pnm")
+    orc.write_pnm(src, orc.synth(rec["W"], rec["H"], rec["C"], rec["seed"], rec["kind"]))
+    r = run(ENC, src, dwt, *([str(rec["capacity"])] if rec["capacity"] else []))
+    assert r.returncode == 0, r.stderr[-300:]
+    assert r.stderr.decode().splitlines() == rec["encode_stderr"]
+    data = open(dwt, "rb").read()
+    assert len(data) == rec["dwt_len"] and hashlib.sha256(data).hexdigest() == rec["dwt_sha256"]
+    r = run(DEC, dwt, pnm, *([str(rec["pixels_arg"])] if rec["pixels_arg"] is not None else []))
+    assert r.returncode == 0, r.stderr[-300:]
+    back = orc.read_pnm(pnm)
+    assert back.shape[:2] == (rec["dec_H"], rec["dec_W"])
+    assert hashlib.sha256(back.tobytes()).hexdigest() == rec["dec_sha256"]
