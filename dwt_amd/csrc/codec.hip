@@ -28,8 +28,8 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 	if (!a || !b)
 		return DWTX_ERR_NOMEM;
 	int rc;
-	if (C == 1 && dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H)) {
-		if ((rc = dwtx_fwd_gray8(ctx, b, dev_pix, W, H, n)))                   // encode.c:155-159 in one pass
+	if (dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C)) {
+		if ((rc = dwtx_fwd_pixels8(ctx, b, dev_pix, W, H, C, n)))              // encode.c:155-159 in one pass
 			return rc;
 	} else {
 		if ((rc = dwtx_planes_from_pixels(ctx, a, dev_pix, W, H, C, n)))       // encode.c:155-156
@@ -95,8 +95,8 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		int r;
 		if ((r = dwtx_reconstruction(ctx, pyr, lin, miss, lo, W, H, C, count)))              // decode.c:257
 			return r;
-		if (C == 1 && dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
-			return dwtx_inv_gray8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, count);   // decode.c:258-264
+		if (dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
+			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count);   // decode.c:258-264
 		if ((r = dwtx_transformation_inv(ctx, img, pyr, ow, oh, count * C)))                 // decode.c:258
 			return r;
 		if (count == 1 || (size_t)ow * oh * C == pix_stride)

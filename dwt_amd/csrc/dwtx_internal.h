@@ -47,12 +47,12 @@ enum {
 	SLOT_LIFT_B = 1,
 };
 
-// lift.hip: the finest lifting level of gray images reads / writes 8-bit pixels itself (the widening of
-// pnm.h:69-74 and the clamp of pnm.h:108 fused into the transform).  dwtx_gray8_ok says whether the
+// lift.hip: the finest lifting level reads / writes 8-bit pixels itself (the widening of pnm.h:69-74, the
+// clamp of pnm.h:108 and, for RGB, the YCoCg-R colour transform of image.h:39-65 fused into it).  dwtx_gray8_ok says whether the
 // shape allows it; image i of the inverse is written at pix + i*image_stride.
 bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
-int dwtx_fwd_gray8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int n);
-int dwtx_inv_gray8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int n);
+int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n);   // C = 3: YCoCg-R fused too (image.h:52-65)
+int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n);   // C = 3: image.h:39-50 fused too
 
 // unpack.hip: dwtx_decode_planes with a host callback per finished part of the batch (see there)
 int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,

@@ -260,7 +260,22 @@ struct FwdRaw {
 	int2 left;        // x[4q-2], x[4q-1] for lane 0
 };
 
-__device__ __forceinline__ FwdRaw fwd_load_w(const int *__restrict__ row, int q, int lane, int nquads, bool valid)
+// Where a forward level reads its samples: int32 planes (every level but possibly the finest), 8-bit
+// gray pixels (pnm.h:69-74 fused) or 8-bit interleaved RGB pixels, of which each plane's launch
+// takes its own YCoCg-R channel (image.h:52-65 fused).
+struct Rgb8 {};
+template <typename SrcT>
+struct SrcTag {};
+template <typename SrcT>
+struct SrcElem {
+	typedef SrcT type;
+};
+template <>
+struct SrcElem<Rgb8> {
+	typedef uint8_t type;
+};
+
+__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<int>, const int *__restrict__ row, int q, int lane, int nquads, bool valid, int)
 {
 	FwdRaw r;
 	r.x = valid ? *reinterpret_cast<const int4 *>(row + 4 * q) : make_int4(0, 0, 0, 0);
@@ -273,7 +288,7 @@ __device__ __forceinline__ FwdRaw fwd_load_w(const int *__restrict__ row, int q,
 	return r;
 }
 
-__device__ __forceinline__ FwdRaw fwd_load_w(const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid)
+__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<uint8_t>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int)
 {
 	FwdRaw r;
 	const unsigned v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
@@ -284,6 +299,39 @@ __device__ __forceinline__ FwdRaw fwd_load_w(const uint8_t *__restrict__ row, in
 		r.xr = row[4 * q + 4];
 	if (lane == 0 && valid && q > 0)
 		r.left = make_int2(row[4 * q - 2], row[4 * q - 1]);
+	return r;
+}
+
+// image.h:52-65: channel ch (0 Y, 1 Co, 2 Cg) of one RGB pixel
+__device__ __forceinline__ int ycocg_of(int r, int g, int b, int ch)
+{
+	const int co = r - b;
+	const int t = b + tdiv2(co);
+	const int cg = g - t;
+	return ch == 0 ? t + tdiv2(cg) : ch == 1 ? co : cg;
+}
+
+__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<Rgb8>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int ch)
+{
+	FwdRaw r;
+	// four pixels = twelve bytes = three aligned words (the row pitch 3*w is a multiple of 4)
+	const unsigned *w = reinterpret_cast<const unsigned *>(row + 12 * q);
+	const unsigned a = valid ? w[0] : 0u, b = valid ? w[1] : 0u, c = valid ? w[2] : 0u;
+	r.x.x = ycocg_of((int)(a & 255u), (int)((a >> 8) & 255u), (int)((a >> 16) & 255u), ch);
+	r.x.y = ycocg_of((int)(a >> 24), (int)(b & 255u), (int)((b >> 8) & 255u), ch);
+	r.x.z = ycocg_of((int)((b >> 16) & 255u), (int)(b >> 24), (int)(c & 255u), ch);
+	r.x.w = ycocg_of((int)((c >> 8) & 255u), (int)((c >> 16) & 255u), (int)(c >> 24), ch);
+	r.xr = 0;
+	r.left = make_int2(0, 0);
+	if (lane == 63 && valid && q + 1 < nquads) {
+		const unsigned n = w[3];
+		r.xr = ycocg_of((int)(n & 255u), (int)((n >> 8) & 255u), (int)((n >> 16) & 255u), ch);
+	}
+	if (lane == 0 && valid && q > 0) {
+		const unsigned m = *(w - 2), n = *(w - 1);   // bytes 12q-8 .. 12q-1: pixels 4q-2 and 4q-1 are the last six
+		r.left = make_int2(ycocg_of((int)((m >> 16) & 255u), (int)(m >> 24), (int)(n & 255u), ch),
+			ycocg_of((int)((n >> 8) & 255u), (int)((n >> 16) & 255u), (int)(n >> 24), ch));
+	}
 	return r;
 }
 
@@ -324,12 +372,22 @@ __device__ __forceinline__ void st2(int *p, I2 v)
 	*reinterpret_cast<int2 *>(p) = make_int2(v.a, v.b);
 }
 
-template <typename SrcT>
-__device__ __forceinline__ const SrcT *fwd_src(const LevelArgs &a);
-template <>
-__device__ __forceinline__ const int *fwd_src<int>(const LevelArgs &a) { return a.src; }
-template <>
-__device__ __forceinline__ const uint8_t *fwd_src<uint8_t>(const LevelArgs &a) { return a.src8; }
+// first sample of the plane's source and the channel a launch extracts (RGB only)
+__device__ __forceinline__ const int *fwd_base(SrcTag<int>, const LevelArgs &a, int plane, int &ch)
+{
+	ch = 0;
+	return a.src + plane * a.src_ps;
+}
+__device__ __forceinline__ const uint8_t *fwd_base(SrcTag<uint8_t>, const LevelArgs &a, int plane, int &ch)
+{
+	ch = 0;
+	return a.src8 + plane * a.src_ps;
+}
+__device__ __forceinline__ const uint8_t *fwd_base(SrcTag<Rgb8>, const LevelArgs &a, int plane, int &ch)
+{
+	ch = plane % 3;
+	return a.src8 + (plane / 3) * a.src_ps;   // src_ps = bytes per interleaved image, spitch = bytes per row
+}
 
 template <typename SrcT>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
@@ -343,23 +401,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	const bool valid = q < A.nquads;
-	const SrcT *src = fwd_src<SrcT>(a) + plane * a.src_ps;
+	int ch;
+	const typename SrcElem<SrcT>::type *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
 	int *ll = a.ll + plane * a.ll_ps;
 	int *det = a.det + plane * a.det_ps;
 
 	int jj = j0 > 0 ? j0 - 1 : 0;
 	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
 	{
-		const FwdRaw r0 = fwd_load_w(src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid);
+		const FwdRaw r0 = fwd_load_w(SrcTag<SrcT>(), src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid, ch);
 		fwd_lift_w(r0, q, lane, A.nquads, l0, h0);
 	}
 	// rows 2jj+1, 2jj+2 of the next two iterations are kept in flight: one wave alone cannot cover
 	// the HBM latency with a single row pair outstanding
 	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
-	FwdRaw n1 = fwd_load_w(rowp(2 * jj + 1), q, lane, A.nquads, valid);
-	FwdRaw n2 = fwd_load_w(rowp(2 * jj + 2), q, lane, A.nquads, valid);
-	FwdRaw m1 = fwd_load_w(rowp(2 * jj + 3), q, lane, A.nquads, valid);
-	FwdRaw m2 = fwd_load_w(rowp(2 * jj + 4), q, lane, A.nquads, valid);
+	FwdRaw n1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 1), q, lane, A.nquads, valid, ch);
+	FwdRaw n2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 2), q, lane, A.nquads, valid, ch);
+	FwdRaw m1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 3), q, lane, A.nquads, valid, ch);
+	FwdRaw m2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 4), q, lane, A.nquads, valid, ch);
 	for (; jj < j1; ++jj) {
 		const int r1 = 2 * jj + 1, r2 = r1 + 1;
 		const bool odd_in = r1 < a.h;
@@ -367,8 +426,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 		n1 = m1;
 		n2 = m2;
 		if (jj + 2 < j1) {
-			m1 = fwd_load_w(rowp(r1 + 4), q, lane, A.nquads, valid);
-			m2 = fwd_load_w(rowp(r2 + 4), q, lane, A.nquads, valid);
+			m1 = fwd_load_w(SrcTag<SrcT>(), rowp(r1 + 4), q, lane, A.nquads, valid, ch);
+			m2 = fwd_load_w(SrcTag<SrcT>(), rowp(r2 + 4), q, lane, A.nquads, valid, ch);
 		}
 		I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
 		if (odd_in)
@@ -519,6 +578,134 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 		dh = ndh;
 		el = nel;
 		eh = neh;
+	}
+}
+
+// The finest inverse level of an RGB image: one wave carries the same columns of the three planes
+// (Y, Co, Cg) and writes interleaved 8-bit pixels — image.h:39-50 ycocg2rgb with its input clamps and
+// the output clamp of pnm.h:108 fused in.  grid.z = image; dst8 rows are 3*w bytes.
+struct Quad4 {
+	int v[4];
+};
+
+__device__ __forceinline__ Quad4 inv_row_vals(int qd, int nquads, I2 lo, I2 hi)
+{
+	int hl = __shfl_up(hi.b, 1);
+	if (qd <= 0)
+		hl = hi.a;
+	const int e0 = lo.a - tdiv4(hl + hi.a);
+	const int e1 = lo.b - tdiv4(hi.a + hi.b);
+	int er = __shfl_down(e0, 1);
+	if (qd + 1 >= nquads)
+		er = e1;
+	Quad4 r;
+	r.v[0] = e0;
+	r.v[1] = hi.a + tdiv2(e0 + e1);
+	r.v[2] = e1;
+	r.v[3] = hi.b + tdiv2(e1 + er);
+	return r;
+}
+
+__device__ __forceinline__ int clamp_to(int v, int lo, int hi)
+{
+	return v < lo ? lo : v > hi ? hi : v;
+}
+
+__device__ __forceinline__ void rgb_store_w(uint8_t *__restrict__ row, int qd, const Quad4 &y, const Quad4 &co, const Quad4 &cg)
+{
+	unsigned char px[12];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int yy = clamp_to(y.v[k], 0, 255), c0 = clamp_to(co.v[k], -255, 255), c1 = clamp_to(cg.v[k], -255, 255);
+		const int t = yy - tdiv2(c1);
+		const int g = c1 + t;
+		const int b = t - tdiv2(c0);
+		const int r = b + c0;
+		px[3 * k] = (unsigned char)clamp_to(r, 0, 255);
+		px[3 * k + 1] = (unsigned char)clamp_to(g, 0, 255);
+		px[3 * k + 2] = (unsigned char)clamp_to(b, 0, 255);
+	}
+	unsigned *w = reinterpret_cast<unsigned *>(row + 12 * qd);
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+		w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+}
+
+__global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
+{
+	const LevelArgs &a = A.a;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int qd = blockIdx.x * INV_QUADS - 1 + lane;
+	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	if (j0 >= a.h2)
+		return;
+	const int j1 = min(j0 + a.rpw, a.h2);
+	const int image = blockIdx.z;
+	const bool valid = qd >= 0 && qd < A.nquads;
+	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
+	const int *llp[3], *det[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		llp[c] = a.src + (long)(3 * image + c) * a.src_ps;
+		det[c] = a.det + (long)(3 * image + c) * a.det_ps;
+	}
+	uint8_t *dst = a.dst8 + image * a.ll_ps;
+	const bool h_odd = a.h & 1;
+
+	auto even_of = [&](int j, I2 s, I2 dprev, I2 dcur) {
+		if (h_odd && 2 * j == a.h - 1)
+			return s;
+		const I2 dp = j ? dprev : dcur;
+		I2 r = { s.a - tdiv4(dp.a + dcur.a), s.b - tdiv4(dp.b + dcur.b) };
+		return r;
+	};
+
+	I2 dl[3], dh[3], el[3], eh[3];
+	InvRaw nxt[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		I2 pdl = { 0, 0 }, pdh = { 0, 0 };
+		if (j0 > 0) {
+			const InvRaw p = inv_load_w(a, llp[c], det[c], j0 - 1, qd, valid);
+			pdl = to_i2(p.dl);
+			pdh = to_i2(p.dh);
+		}
+		const InvRaw cur = inv_load_w(a, llp[c], det[c], j0, qd, valid);
+		nxt[c] = inv_load_w(a, llp[c], det[c], j0 + 1, qd, valid);
+		dl[c] = to_i2(cur.dl);
+		dh[c] = to_i2(cur.dh);
+		el[c] = even_of(j0, to_i2(cur.sl), pdl, dl[c]);
+		eh[c] = even_of(j0, to_i2(cur.sh), pdh, dh[c]);
+	}
+	for (int jj = j0; jj < j1; ++jj) {
+		const int r0 = 2 * jj, r1 = r0 + 1;
+		Quad4 even[3], odd[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const InvRaw n = nxt[c];
+			if (jj + 1 < j1)
+				nxt[c] = inv_load_w(a, llp[c], det[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
+			I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el[c], neh = eh[c];     // mirror x[h] := x[h-2]
+			if (r1 + 1 < a.h) {
+				ndl = to_i2(n.dl);
+				ndh = to_i2(n.dh);
+				nel = even_of(jj + 1, to_i2(n.sl), dl[c], ndl);
+				neh = even_of(jj + 1, to_i2(n.sh), dh[c], ndh);
+			}
+			even[c] = inv_row_vals(qd, A.nquads, el[c], eh[c]);
+			const I2 ol = { dl[c].a + tdiv2(el[c].a + nel.a), dl[c].b + tdiv2(el[c].b + nel.b) };
+			const I2 oh = { dh[c].a + tdiv2(eh[c].a + neh.a), dh[c].b + tdiv2(eh[c].b + neh.b) };
+			odd[c] = inv_row_vals(qd, A.nquads, ol, oh);
+			dl[c] = ndl;
+			dh[c] = ndh;
+			el[c] = nel;
+			eh[c] = neh;
+		}
+		if (writes) {
+			rgb_store_w(dst + (long)r0 * a.llpitch, qd, even[0], even[1], even[2]);
+			if (r1 < a.h)
+				rgb_store_w(dst + (long)r1 * a.llpitch, qd, odd[0], odd[1], odd[2]);
+		}
 	}
 }
 
@@ -814,8 +1001,9 @@ static int pick_rpw(int strips_x, int h2, int nplanes)
 	return rpw;
 }
 
-// in8 != nullptr: the planes are 8-bit gray images (W*H bytes each); needs a finest level the wide kernel takes
-static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int W, int H, int nplanes)
+// in8 != nullptr: the source is 8-bit pixels, gray (in8_channels 1: plane p = image p) or interleaved RGB
+// (in8_channels 3: plane p = channel p%3 of image p/3 after YCoCg-R); needs a finest level the wide kernel takes
+static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int in8_channels, int W, int H, int nplanes)
 {
 	if (!ctx || !out || (!in && !in8) || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -887,8 +1075,8 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 		a.src = bytes_in ? nullptr : src;
 		a.src8 = bytes_in ? in8 : nullptr;
 		a.dst8 = nullptr;
-		a.src_ps = src_ps;
-		a.spitch = spitch;
+		a.src_ps = bytes_in ? (long)in8_channels * full_ps : src_ps;
+		a.spitch = bytes_in ? in8_channels * W : spitch;
 		ll_dest(t + 1, a.ll, a.ll_ps, a.llpitch);
 		a.det = out;
 		a.det_ps = full_ps;
@@ -906,7 +1094,9 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
-			if (bytes_in)
+			if (bytes_in && in8_channels == 3)
+				hipLaunchKernelGGL(k_fwd_level_w<Rgb8>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else if (bytes_in)
 				hipLaunchKernelGGL(k_fwd_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
 				hipLaunchKernelGGL(k_fwd_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
@@ -929,7 +1119,7 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 {
 	if (!in)
 		return DWTX_ERR_ARG;
-	return lift_fwd(ctx, out, in, nullptr, W, H, nplanes);
+	return lift_fwd(ctx, out, in, nullptr, 0, W, H, nplanes);
 }
 
 // Can the finest level of a W*H gray image read / write 8-bit pixels directly?  (wide kernel, not the LDS tail)
@@ -938,15 +1128,16 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride)
 	return W % 4 == 0 && (W > TAIL_MAX || H > TAIL_MAX) && image_stride % 4 == 0 && aligned_to(pix, 4);
 }
 
-int dwtx_fwd_gray8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int n)
+int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n)
 {
-	if (!pix || W < 2 || H < 2 || !dwtx_gray8_ok(W, H, pix, (size_t)W * H))
+	if (!pix || W < 2 || H < 2 || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, (size_t)W * H * C))
 		return DWTX_ERR_ARG;
-	return lift_fwd(ctx, out, nullptr, pix, W, H, n);
+	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C);
 }
 
-// out8 != nullptr: the finest level writes clamped 8-bit pixels, image i at out8 + i*out8_ps
-static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, const int32_t *in, int W, int H, int nplanes)
+// out8 != nullptr: the finest level writes clamped 8-bit pixels (gray, or interleaved RGB after the
+// inverse colour transform when out8_channels == 3), image i at out8 + i*out8_ps
+static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, int out8_channels, const int32_t *in, int W, int H, int nplanes)
 {
 	if (!ctx || (!out && !out8) || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -1015,7 +1206,7 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, co
 			a.ll = nullptr;
 			a.dst8 = out8;
 			a.ll_ps = out8_ps;
-			a.llpitch = W;
+			a.llpitch = out8_channels * W;
 		} else if (t == 0) {
 			a.ll = out;
 			a.ll_ps = full_ps;
@@ -1041,7 +1232,10 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, co
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
-			if (bytes_out)
+			if (bytes_out && out8_channels == 3) {
+				grid.z = nplanes / 3;
+				hipLaunchKernelGGL(k_inv_level_w_rgb, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			} else if (bytes_out)
 				hipLaunchKernelGGL(k_inv_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
 				hipLaunchKernelGGL(k_inv_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
@@ -1060,12 +1254,12 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 {
 	if (!out)
 		return DWTX_ERR_ARG;
-	return lift_inv(ctx, out, nullptr, 0, in, W, H, nplanes);
+	return lift_inv(ctx, out, nullptr, 0, 0, in, W, H, nplanes);
 }
 
-int dwtx_inv_gray8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int n)
+int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n)
 {
-	if (!pix || W < 2 || H < 2 || !dwtx_gray8_ok(W, H, pix, image_stride))
+	if (!pix || W < 2 || H < 2 || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, image_stride))
 		return DWTX_ERR_ARG;
-	return lift_inv(ctx, nullptr, pix, (long)image_stride, in, W, H, n);
+	return lift_inv(ctx, nullptr, pix, (long)image_stride, C, in, W, H, n * C);
 }

@@ -148,12 +148,14 @@ def test_device_resident_roundtrip(ctx):
         assert streams[i, : int(lens[i])].cpu().numpy().tobytes() == orc.encode(host[i])[0]
 
 
-@pytest.mark.parametrize("shape", [(117, 200, 1), (72, 68, 1), (64, 128, 1), (255, 512, 1), (600, 36, 1)])
-def test_gray_pixels_straight_into_the_lifting(ctx, shape):
-    """W % 4 == 0 gray images skip the int widening / clamp passes (pnm.h:69-74,108 fused into the finest
-    lifting level); same bytes, full and cut short, with odd heights and levels that fall back."""
+@pytest.mark.parametrize("shape", [(117, 200, 1), (72, 68, 1), (64, 128, 1), (255, 512, 1), (600, 36, 1),
+                                   (117, 200, 3), (72, 68, 3), (65, 132, 3), (301, 44, 3)])
+def test_pixels_straight_into_the_lifting(ctx, shape):
+    """W % 4 == 0 images skip the int widening / colour / clamp passes (pnm.h:69-74,108 and image.h:39-65
+    fused into the finest lifting level); same bytes, full and cut short, with odd heights and levels
+    that fall back, on smooth and on noise frames (the clamps matter on truncated noise)."""
     H, W, Cn = shape
-    pix = orc.synth(W, H, Cn, 3, 0)
+    pix = orc.synth(W, H, Cn, 3, (H + Cn) & 1)
     full, _ = ctx.encode(pix)
     assert full == orc.encode(pix)[0]
     assert (ctx.decode(full) == pix).all()
