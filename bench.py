@@ -165,7 +165,7 @@ def main():
     golden_ok = None
     if rank == 0:
         gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
-        gname = {"gray4096": "g4096x4096", "rgb1080p": "c1920x1080"}.get(args.workload)
+        gname = {"gray4096": "g4096x4096", "rgb1080p": "c1920x1080", "rgb4096": "c4096x4096"}.get(args.workload)
         if gname and os.path.exists(gpath):
             rec = json.load(open(gpath))[gname]
             s0 = streams[0, : lens_host[0]].cpu().numpy().tobytes()

@@ -40,6 +40,8 @@ CASES = [
     ("c1920x1080", 1920, 1080, 3, 0, 0, 0, None),
     ("g4096x4096", 4096, 4096, 1, 0, 0, 0, None),
     ("c1920x1080_cap65536", 1920, 1080, 3, 0, 0, 65536, None),
+    ("c4096x4096", 4096, 4096, 3, 0, 0, 0, None),          # one frame of BASELINE.json configs[4]
+    ("c4096x4096_px70000", 4096, 4096, 3, 0, 0, 0, 70000),
 ]
 # BASELINE.json configs[3]: ~3 minutes and ~10 GB of RAM with the reference; only with DWT_GOLDEN_HEAVY=1
 HEAVY = [("c16384x16384_cap1MiB", 16384, 16384, 3, 0, 0, 1048576, None)]

@@ -34,6 +34,8 @@ def test_golden_encode_decode(name):
         pytest.skip("heavy golden (minutes of CPU): covered by the GPU test")
     if name not in SMALL and os.environ.get("DWT_FULL_GOLDEN", "1") == "0":
         pytest.skip("large golden skipped")
+    if rec["W"] * rec["H"] * rec["C"] > 20_000_000:
+        pytest.skip("config E frame (tens of seconds on the CPU): covered by the GPU test")
     pix = case_input(rec)
     assert sha(pix.tobytes()) == rec["input_sha256"], "synthetic generator drifted"
     data, st = orc.encode(pix, rec["capacity"])
