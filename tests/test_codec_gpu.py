@@ -62,7 +62,8 @@ def test_goldens_from_the_real_reference(ctx, name):
     assert sha(back.tobytes()) == rec["dec_sha256"]
 
 
-@pytest.mark.parametrize("shape", [(8, 8, 1), (9, 8, 3), (77, 131, 3), (300, 17, 1), (255, 257, 3), (33, 1000, 1)])
+@pytest.mark.parametrize("shape", [(8, 8, 1), (9, 8, 3), (77, 131, 3), (300, 17, 1), (255, 257, 3), (33, 1000, 1),
+                                   (700, 1000, 3), (1025, 2047, 1), (1030, 1548, 3)])
 def test_roundtrip_and_oracle_bytes(ctx, shape):
     H, W, Cn = shape
     for kind in (0, 1):
@@ -182,3 +183,25 @@ def test_gray_batch_both_halves_and_mixed_lengths(ctx):
     for i in range(n):
         want = orc.decode(streams[i])
         assert outs[i].shape == want.shape and (outs[i] == want).all()
+
+
+def test_random_shapes_capacities_and_cuts(ctx):
+    """Seeded sweep over small random geometries (odd sizes, widths that do and do not take the fused
+    pixel paths), capacities, stream cuts and PIXELS caps: bytes and pictures equal the oracle's."""
+    rng = np.random.default_rng(20260101)
+    for case in range(48):
+        W, H = int(rng.integers(8, 161)), int(rng.integers(8, 161))
+        if case % 3 == 0:
+            W = (W + 3) // 4 * 4
+        Cn = 1 if rng.integers(0, 2) else 3
+        pix = orc.synth(W, H, Cn, 1000 + case, int(rng.integers(0, 2)))
+        full, _ = ctx.encode(pix)
+        assert full == orc.encode(pix)[0], (W, H, Cn)
+        assert (ctx.decode(full) == pix).all(), (W, H, Cn)
+        cap = int(rng.integers(40, max(41, len(full))))
+        data, _ = ctx.encode(pix, cap)
+        assert data == full[:cap], (W, H, Cn, cap)
+        for blob, px in ((data, None), (full, int(rng.integers(0, 4 * W * H))), (full[: len(full) // 2], 200)):
+            want = orc.decode(blob, -1 if px is None else px)
+            got = ctx.decode(blob, -1 if px is None else px)
+            assert (want is None and got is None) or (got.shape == want.shape and (got == want).all()), (W, H, Cn, cap, px)
