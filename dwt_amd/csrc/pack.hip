@@ -110,6 +110,7 @@ struct Work {
 	RunMap *carry_agg;                 // [n][NCB] map of each block of 1024 entries
 	unsigned *carry_in;                // [n][NCB] pending run entering the block
 	unsigned *ent_blk;                 // [n][NCB][2] token slots / refinement bits of each block of 1024 entries, then their scan
+	unsigned long long *stream_bits;   // [n] bits of the whole stream before any capacity clip (k_bitscan -> k_clear_stream)
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
 	long ES, TS, NCS, NGS, NCB;
 	int NT;
@@ -1279,6 +1280,7 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 	}
 	if (threadIdx.x == 0) {
 		const unsigned long long bits = carry;
+		w.stream_bits[img] = bits;
 		unsigned long long bytes = (bits + 7) >> 3;
 		// bytes.h:75-78: nothing is written past `capacity` bytes; the stream is a prefix
 		I.total_bits = bits;
@@ -1291,6 +1293,28 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 		}
 		I.nbytes = bytes;
 		I.pad = w.slow[img];   // 1: the exact 32-state order pass had to run for this image
+	}
+}
+
+// The token and refinement writers OR their bits into the stream, so it has to start as zeros — but only
+// the words the stream will occupy (its length is known after k_bitscan), not the whole output stride;
+// the words k_plan filled with header, root image and plane counts stay.
+__global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, long out_words)
+{
+	const int img = blockIdx.y;
+	const long first = ((long)w.info[img].hdr_bits + 31) >> 5;
+	long last = (long)((w.stream_bits[img] + 31) >> 5) + 4;
+	last = last < out_words ? last : out_words;
+	const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i >= last || i + 4 <= first)
+		return;
+	unsigned *dst = out + img * out_words + i;
+	if (i >= first && i + 4 <= last) {
+		*reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+	} else {
+		for (int k = 0; k < 4; ++k)
+			if (i + k >= first && i + k < last)
+				dst[k] = 0u;
 	}
 }
 
@@ -1424,6 +1448,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_planes = take(sizeof(int) * nplanes);
 		const size_t o_info = take(sizeof(ImgInfo) * n);
 		const size_t o_slow = take(sizeof(int) * n);
+		const size_t o_sbits = take(sizeof(unsigned long long) * n);
 		const size_t o_sd = take(sizeof(int) * (size_t)n * MAX_SEGS);
 		const size_t o_eb = take(sizeof(int) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
@@ -1436,6 +1461,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.planes_dev = (int *)(small + o_planes);
 		w.info = (ImgInfo *)(small + o_info);
 		w.slow = (int *)(small + o_slow);
+		w.stream_bits = (unsigned long long *)(small + o_sbits);
 		w.seg_desc = (int *)(small + o_sd);
 		w.seg_ebase = (int *)(small + o_eb);
 		w.seg_refs = (unsigned *)(small + o_sr);
@@ -1501,7 +1527,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipStream_t s = ctx->stream;
 	const long out_words = (long)(out_stride / 4);
 	unsigned *outw = (unsigned *)out;
-	DWTX_HIP(hipMemsetAsync(out, 0, out_stride * (size_t)n, s));
+	// k_plan stores the first words (header, root image, plane counts) outright; the rest of the stream is
+	// cleared by k_clear_stream once its length is known
 
 	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
@@ -1520,6 +1547,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
 	hipLaunchKernelGGL(k_orders, dim3(512, n), dim3(64 * ORD_WAVES), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
+	hipLaunchKernelGGL(k_clear_stream, dim3((unsigned)((out_words / 4 + 256) / 256), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / (64 * EMIT_TOK) + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
