@@ -62,6 +62,8 @@ SYMBOLS = {
     "dwtx_stream": (_vp, [_vp]),
     "dwtx_malloc": (_vp, [_vp, _sz]),
     "dwtx_free": (None, [_vp, _vp]),
+    "dwtx_host_alloc": (_vp, [_vp, _sz]),
+    "dwtx_host_free": (None, [_vp, _vp]),
     "dwtx_upload": (_i, [_vp, _vp, _vp, _sz]),
     "dwtx_download": (_i, [_vp, _vp, _vp, _sz]),
     "dwtx_compute_lengths": (_i, [C.POINTER(_i)] * 4 + [_i, _i, _i]),

@@ -127,59 +127,122 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		[](void *user, int first, int count) { return (*(Part *)user)(first, count); }, &part);
 }
 
-// ---- host-buffer convenience wrappers (what the CLIs call) --------------------
+// ---- host-buffer wrappers (what the CLIs call) ---------------------------------
+// A batch is cut into parts of at most part_size() images.  Part k's kernels run on the context's
+// stream while part k+1's input is on its way in and part k-1's output on its way out (a second
+// stream, two device staging buffers each way): device memory stays bounded for any n, and with
+// page-locked host buffers (dwtx_host_alloc) the PCIe transfers hide behind the kernels.
+
+static int part_size(int W, int H, int C, int n)
+{
+	const size_t samples = (size_t)W * H * C;
+	size_t p = ((size_t)64 << 20) / (samples ? samples : 1);   // about 64 M samples per part (16 frames of 4096x4096 gray)
+	p = p < 4 ? 4 : p > 256 ? 256 : p;
+	if (const char *env = getenv("DWTX_PART_IMAGES"))   // test hook: force small parts
+		p = atoi(env) > 0 ? (size_t)atoi(env) : p;
+	return (size_t)n < p ? n : (int)p;
+}
+
+static int sync_all(dwtx_ctx *ctx)
+{
+	hipError_t a = hipStreamSynchronize(ctx->stream);
+	hipError_t b = ctx->have_copy ? hipStreamSynchronize(ctx->copy) : hipSuccess;
+	return a == hipSuccess && b == hipSuccess ? DWTX_OK : DWTX_ERR_DEVICE;
+}
 
 extern "C" int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *pix, int W, int H, int C, int n, long capacity,
 	uint8_t *out, size_t out_stride, size_t *out_lens, dwtx_stats *stats)
 {
-	if (!ctx || !pix || !out || !out_lens || (out_stride & 7))
+	if (!ctx || !pix || !out || !out_lens || (out_stride & 7) || n < 1 || W < 1 || H < 1 || (C != 1 && C != 3))
 		return DWTX_ERR_ARG;
-	const size_t in_bytes = (size_t)W * H * C * n;
-	uint8_t *dpix = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO, in_bytes);
-	uint8_t *dout = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO2, out_stride * (size_t)n);
-	dwtx_stream_info *dinfo = (dwtx_stream_info *)dwtx_scratch(ctx, SLOT_CD_LENS, sizeof(dwtx_stream_info) * (size_t)n);
-	if (!dpix || !dout || !dinfo)
-		return DWTX_ERR_NOMEM;
-	DWTX_HIP(hipMemcpyAsync(dpix, pix, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-	int rc = dwtx_encode_device(ctx, dpix, W, H, C, n, capacity, dout, out_stride, dinfo);
+	const int P = part_size(W, H, C, n), parts = (n + P - 1) / P;
+	const size_t img_bytes = (size_t)W * H * C;
+	int rc = dwtx_need_copy_stream(ctx);
 	if (rc)
 		return rc;
-	dwtx_stream_info *hinfo = (dwtx_stream_info *)malloc(sizeof(dwtx_stream_info) * (size_t)n);
-	if (!hinfo)
+	uint8_t *dpix = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO, 2 * img_bytes * P);
+	uint8_t *dout = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO2, 2 * out_stride * (size_t)P);
+	dwtx_stream_info *dinfo = (dwtx_stream_info *)dwtx_scratch(ctx, SLOT_CD_LENS, 2 * sizeof(dwtx_stream_info) * (size_t)P);
+	dwtx_stream_info *hinfo = nullptr;   // page-locked: its copy must not block the host
+	if (hipHostMalloc((void **)&hinfo, 2 * sizeof(dwtx_stream_info) * (size_t)P, hipHostMallocDefault) != hipSuccess)
+		hinfo = nullptr;
+	if (!dpix || !dout || !dinfo || !hinfo) {
+		if (hinfo)
+			(void)hipHostFree(hinfo);
 		return DWTX_ERR_NOMEM;
-	hipError_t e = hipMemcpyAsync(hinfo, dinfo, sizeof(dwtx_stream_info) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(ctx->stream);
-	rc = DWTX_OK;
-	for (int i = 0; e == hipSuccess && i < n; ++i) {
-		if (hinfo[i].error) {
-			dwtx_set_error("image %d needs more than 16 bit planes", i);
-			rc = DWTX_ERR_ARG;
-			break;
-		}
-		if (hinfo[i].nbytes > out_stride) {
-			dwtx_set_error("image %d: stream of %llu bytes exceeds out_stride %zu", i, hinfo[i].nbytes, out_stride);
-			rc = DWTX_ERR_CAPACITY;
-			break;
-		}
-		out_lens[i] = (size_t)hinfo[i].nbytes;
-		e = hipMemcpyAsync(out + out_stride * i, dout + out_stride * i, (size_t)hinfo[i].nbytes, hipMemcpyDeviceToHost,
-			ctx->stream);
-		if (stats) {
-			stats[i].meta_bits = 48;                                   // encode.c:175
-			stats[i].root_bits = (int)hinfo[i].root_bits;              // encode.c:179
-			stats[i].total_bits = (int)hinfo[i].total_bits;            // encode.c:226 (int there too)
-			stats[i].kib = (int)((hinfo[i].nbytes + 512) / 1024);      // encode.c:228
-			stats[i].levels = 0;
-			for (int c = 0; c < 3; ++c)
-				stats[i].planes[c] = hinfo[i].planes[c];
-		}
 	}
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(ctx->stream);
-	free(hinfo);
-	if (e != hipSuccess) {
-		dwtx_set_error("encode_images copy -> %s", hipGetErrorString(e));
+	hipStream_t ms = ctx->stream, cs = ctx->copy;
+	hipEvent_t *ev_in = ctx->cev, *ev_enc = ctx->cev + 2, *ev_out = ctx->cev + 4;   // per staging slot
+	hipError_t e = hipSuccess;
+	rc = DWTX_OK;
+	auto first_of = [&](int k) { return k * P; };
+	auto count_of = [&](int k) { return k == parts - 1 ? n - k * P : P; };
+	// part k's streams to the host, once its lengths are known
+	auto drain = [&](int k) {
+		const int slot = k & 1, i0 = first_of(k), cnt = count_of(k);
+		const dwtx_stream_info *hi = hinfo + (size_t)slot * P;
+		e = hipEventSynchronize(ev_enc[slot]);
+		for (int i = 0; e == hipSuccess && rc == DWTX_OK && i < cnt; ++i) {
+			if (hi[i].error) {
+				dwtx_set_error("image %d needs more than 16 bit planes", i0 + i);
+				rc = DWTX_ERR_ARG;
+				break;
+			}
+			if (hi[i].nbytes > out_stride) {
+				dwtx_set_error("image %d: stream of %llu bytes exceeds out_stride %zu", i0 + i, hi[i].nbytes, out_stride);
+				rc = DWTX_ERR_CAPACITY;
+				break;
+			}
+			out_lens[i0 + i] = (size_t)hi[i].nbytes;
+			e = hipMemcpyAsync(out + out_stride * (i0 + i), dout + out_stride * ((size_t)slot * P + i), (size_t)hi[i].nbytes,
+				hipMemcpyDeviceToHost, cs);
+			if (stats) {
+				dwtx_stats &st = stats[i0 + i];
+				st.meta_bits = 48;                                   // encode.c:175
+				st.root_bits = (int)hi[i].root_bits;                 // encode.c:179
+				st.total_bits = (int)hi[i].total_bits;               // encode.c:226 (int there too)
+				st.kib = (int)((hi[i].nbytes + 512) / 1024);         // encode.c:228
+				st.levels = 0;
+				for (int c = 0; c < 3; ++c)
+					st.planes[c] = hi[i].planes[c];
+			}
+		}
+		if (e == hipSuccess)
+			e = hipEventRecord(ev_out[slot], cs);
+	};
+	for (int k = 0; k < parts && e == hipSuccess && rc == DWTX_OK; ++k) {
+		const int slot = k & 1, i0 = first_of(k), cnt = count_of(k);
+		if (k >= 2) {
+			e = hipStreamWaitEvent(cs, ev_enc[slot], 0);     // part k-2 has read this pixel buffer
+			if (e == hipSuccess)
+				e = hipStreamWaitEvent(ms, ev_out[slot], 0); // and its streams have left this output buffer
+		}
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dpix + (size_t)slot * P * img_bytes, pix + (size_t)i0 * img_bytes, img_bytes * cnt,
+				hipMemcpyHostToDevice, cs);
+		if (e == hipSuccess)
+			e = hipEventRecord(ev_in[slot], cs);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(ms, ev_in[slot], 0);
+		if (e != hipSuccess)
+			break;
+		rc = dwtx_encode_device(ctx, dpix + (size_t)slot * P * img_bytes, W, H, C, cnt, capacity,
+			dout + out_stride * (size_t)slot * P, out_stride, dinfo + (size_t)slot * P);
+		if (rc)
+			break;
+		e = hipMemcpyAsync(hinfo + (size_t)slot * P, dinfo + (size_t)slot * P, sizeof(dwtx_stream_info) * (size_t)cnt,
+			hipMemcpyDeviceToHost, ms);
+		if (e == hipSuccess)
+			e = hipEventRecord(ev_enc[slot], ms);
+		if (k >= 1 && e == hipSuccess)
+			drain(k - 1);   // overlaps part k's kernels
+	}
+	if (e == hipSuccess && rc == DWTX_OK)
+		drain(parts - 1);
+	const int s = sync_all(ctx);
+	(void)hipHostFree(hinfo);
+	if (e != hipSuccess || s) {
+		dwtx_set_error("encode_images transfer -> %s", hipGetErrorString(e));
 		return DWTX_ERR_DEVICE;
 	}
 	return rc;
@@ -211,9 +274,14 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 		while (levels_max > 0 && g.pixels[levels_max] > pixels_max)
 			--levels_max;
 	}
-	uint8_t *dstr = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO, stream_stride * (size_t)n + 64);
-	uint8_t *dpix = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO2, (size_t)W * H * C * n);
-	unsigned long long *dlens = (unsigned long long *)dwtx_scratch(ctx, SLOT_CD_LENS, sizeof(unsigned long long) * (size_t)n);
+	const int P = part_size(W, H, C, n), parts = (n + P - 1) / P;
+	const size_t img_bytes = (size_t)W * H * C;
+	int rc = dwtx_need_copy_stream(ctx);
+	if (rc)
+		return rc;
+	uint8_t *dstr = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO, 2 * stream_stride * (size_t)P + 64);
+	uint8_t *dpix = (uint8_t *)dwtx_scratch(ctx, SLOT_CD_IO2, 2 * img_bytes * P);
+	unsigned long long *dlens = (unsigned long long *)dwtx_scratch(ctx, SLOT_CD_LENS, 2 * sizeof(unsigned long long) * (size_t)P);
 	unsigned long long *hl = (unsigned long long *)malloc(sizeof(unsigned long long) * (size_t)n);
 	dwtx_decode_info *info = (dwtx_decode_info *)malloc(sizeof(dwtx_decode_info) * (size_t)n);
 	if (!dstr || !dpix || !dlens || !hl || !info) {
@@ -223,34 +291,68 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 	}
 	for (int i = 0; i < n; ++i)
 		hl[i] = lens[i];
-	int rc = DWTX_OK;
-	hipError_t e = hipMemcpyAsync(dstr, streams, stream_stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(dlens, hl, sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
-	if (e == hipSuccess)
-		rc = dwtx_decode_device(ctx, dstr, stream_stride, dlens, W, H, C, n, levels_max, dpix, (size_t)W * H * C, info);
-	for (int i = 0; e == hipSuccess && rc == DWTX_OK && i < n; ++i) {
-		if (info[i].status) {
-			outW[i] = outH[i] = 0;
-			outC[i] = C;
-			rc = n == 1 ? DWTX_ERR_IO : rc;   // decode.c:181,185: unreadable root/planes -> exit 1
-			continue;
+	hipStream_t ms = ctx->stream, cs = ctx->copy;
+	hipEvent_t *ev_in = ctx->cev, *ev_dec = ctx->cev + 2, *ev_out = ctx->cev + 4;   // per staging slot
+	hipError_t e = hipSuccess;
+	rc = DWTX_OK;
+	auto count_of = [&](int k) { return k == parts - 1 ? n - k * P : P; };
+	// part k's streams and lengths to the device (copy stream)
+	auto feed = [&](int k) {
+		const int slot = k & 1, i0 = k * P, cnt = count_of(k);
+		if (k >= 2)
+			e = hipStreamWaitEvent(cs, ev_dec[slot], 0);   // part k-2 has read this staging buffer
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dstr + stream_stride * (size_t)slot * P, streams + stream_stride * (size_t)i0, stream_stride * (size_t)cnt,
+				hipMemcpyHostToDevice, cs);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dlens + (size_t)slot * P, hl + i0, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyHostToDevice, cs);
+		if (e == hipSuccess)
+			e = hipEventRecord(ev_in[slot], cs);
+	};
+	feed(0);
+	for (int k = 0; k < parts && e == hipSuccess; ++k) {
+		const int slot = k & 1, i0 = k * P, cnt = count_of(k);
+		if (k + 1 < parts)
+			feed(k + 1);   // travels while part k is decoded
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(ms, ev_in[slot], 0);
+		if (e == hipSuccess && k >= 2)
+			e = hipStreamWaitEvent(ms, ev_out[slot], 0);   // part k-2's pixels have left this buffer
+		if (e != hipSuccess)
+			break;
+		const int r = dwtx_decode_device(ctx, dstr + stream_stride * (size_t)slot * P, stream_stride, dlens + (size_t)slot * P, W, H, C, cnt,
+			levels_max, dpix + img_bytes * (size_t)slot * P, img_bytes, info + i0);
+		if (r) {
+			rc = r;
+			break;
 		}
-		const int lo = info[i].level + 1;
-		outW[i] = g.widths[lo];
-		outH[i] = g.heights[lo];
-		outC[i] = C;
-		e = hipMemcpyAsync(pix + pix_stride * i, dpix + (size_t)W * H * C * i, (size_t)outW[i] * outH[i] * C,
-			hipMemcpyDeviceToHost, ctx->stream);
+		e = hipEventRecord(ev_dec[slot], ms);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(cs, ev_dec[slot], 0);
+		for (int i = 0; e == hipSuccess && i < cnt; ++i) {
+			const dwtx_decode_info &I = info[i0 + i];
+			outC[i0 + i] = C;
+			if (I.status) {
+				outW[i0 + i] = outH[i0 + i] = 0;
+				rc = n == 1 ? DWTX_ERR_IO : rc;   // decode.c:181,185: unreadable root/planes -> exit 1
+				continue;
+			}
+			const int lo = I.level + 1;
+			outW[i0 + i] = g.widths[lo];
+			outH[i0 + i] = g.heights[lo];
+			e = hipMemcpyAsync(pix + pix_stride * (size_t)(i0 + i), dpix + img_bytes * ((size_t)slot * P + i),
+				(size_t)outW[i0 + i] * outH[i0 + i] * C, hipMemcpyDeviceToHost, cs);
+		}
+		if (e == hipSuccess)
+			e = hipEventRecord(ev_out[slot], cs);
 	}
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(ctx->stream);
-	if (infos && e == hipSuccess && (rc == DWTX_OK || rc == DWTX_ERR_IO))
+	const int s = sync_all(ctx);
+	if (infos && e == hipSuccess && !s && (rc == DWTX_OK || rc == DWTX_ERR_IO))
 		memcpy(infos, info, sizeof(dwtx_decode_info) * (size_t)n);
 	free(hl);
 	free(info);
-	if (e != hipSuccess) {
-		dwtx_set_error("decode_images copy -> %s", hipGetErrorString(e));
+	if (e != hipSuccess || s) {
+		dwtx_set_error("decode_images transfer -> %s", hipGetErrorString(e));
 		return DWTX_ERR_DEVICE;
 	}
 	return rc;

@@ -77,9 +77,49 @@ extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 		(void)hipEventDestroy(c->ev[0]);
 		(void)hipEventDestroy(c->ev[1]);
 	}
+	if (c->have_copy) {
+		(void)hipStreamDestroy(c->copy);
+		for (int i = 0; i < 6; ++i)
+			(void)hipEventDestroy(c->cev[i]);
+	}
 	if (c->own_stream)
 		(void)hipStreamDestroy(c->stream);
 	free(c);
+}
+
+int dwtx_need_copy_stream(dwtx_ctx *c)
+{
+	if (c->have_copy)
+		return DWTX_OK;
+	DWTX_HIP(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+	for (int i = 0; i < 6; ++i)
+		DWTX_HIP(hipEventCreateWithFlags(&c->cev[i], hipEventDisableTiming));
+	c->have_copy = true;
+	return DWTX_OK;
+}
+
+// Page-locked host memory: transfers from/to it run asynchronously, so the host-buffer entry points can
+// overlap them with kernels (pageable buffers work too, the runtime then stages them).
+extern "C" void *dwtx_host_alloc(dwtx_ctx *c, size_t bytes)
+{
+	void *p = nullptr;
+	(void)hipSetDevice(c->device);
+	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		dwtx_set_error("hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void dwtx_host_free(dwtx_ctx *c, void *host)
+{
+	if (!host)
+		return;
+	(void)hipStreamSynchronize(c->stream);
+	if (c->have_copy)
+		(void)hipStreamSynchronize(c->copy);
+	(void)hipHostFree(host);
 }
 
 extern "C" int dwtx_sync(dwtx_ctx *c)

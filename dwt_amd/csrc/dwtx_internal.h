@@ -20,9 +20,13 @@ struct dwtx_ctx {
 	hipStream_t aux;       // second stream: half of a decode batch runs here so that one half's serial
 	hipEvent_t ev[2];      // token walk overlaps the other half's parallel kernels (unpack.hip)
 	bool have_aux;
+	hipStream_t copy;      // host-buffer wrappers: transfers of one part of a batch overlap the kernels of another (codec.hip)
+	hipEvent_t cev[6];
+	bool have_copy;
 };
 
 void dwtx_free_plans(dwtx_ctx *ctx);
+int dwtx_need_copy_stream(dwtx_ctx *ctx);   // creates ctx->copy / ctx->cev on first use
 
 void dwtx_set_error(const char *fmt, ...);
 // grow-only per-slot device scratch; contents undefined after a grow

@@ -110,6 +110,10 @@ void *dwtx_stream(dwtx_ctx *ctx);
 
 void *dwtx_malloc(dwtx_ctx *ctx, size_t bytes);
 void dwtx_free(dwtx_ctx *ctx, void *dev);
+/* Page-locked host memory for the host-buffer entry points below: their transfers then overlap the
+ * kernels of the previous part of the batch (pageable buffers work too, only slower). */
+void *dwtx_host_alloc(dwtx_ctx *ctx, size_t bytes);
+void dwtx_host_free(dwtx_ctx *ctx, void *host);
 int dwtx_upload(dwtx_ctx *ctx, void *dev, const void *host, size_t bytes);
 int dwtx_download(dwtx_ctx *ctx, void *host, const void *dev, size_t bytes);
 

@@ -205,3 +205,22 @@ def test_random_shapes_capacities_and_cuts(ctx):
             want = orc.decode(blob, -1 if px is None else px)
             got = ctx.decode(blob, -1 if px is None else px)
             assert (want is None and got is None) or (got.shape == want.shape and (got == want).all()), (W, H, Cn, cap, px)
+
+
+def test_host_batches_pipeline_in_parts(ctx, monkeypatch):
+    """The host-buffer entry points cut a batch into parts whose transfers overlap the neighbouring
+    parts' kernels; with parts of 3 images an 11-image batch takes four of them (both staging slots
+    get reused), one stream cut short."""
+    monkeypatch.setenv("DWTX_PART_IMAGES", "3")
+    n, H, W, Cn = 11, 72, 100, 3
+    pix = np.stack([orc.synth(W, H, Cn, 500 + i, i & 1) for i in range(n)])
+    streams, stats = ctx.encode(pix)
+    for i in range(n):
+        want, ost = orc.encode(pix[i])
+        assert streams[i] == want
+        assert (stats[i].root_bits, stats[i].total_bits) == (ost.root_bits, ost.total_bits)
+    streams[7] = streams[7][: len(streams[7]) // 4]
+    outs = ctx.decode(streams)
+    for i in range(n):
+        want = orc.decode(streams[i])
+        assert outs[i].shape == want.shape and (outs[i] == want).all()
