@@ -320,6 +320,54 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 	const bool up = lane >= 32;
 	const unsigned winA = __builtin_amdgcn_alignbit(up ? d2 : d1, up ? d1 : d0, (unsigned)lane & 31u);
 	const unsigned winB = __builtin_amdgcn_alignbit(up ? d4 : d3, up ? d3 : d2, (unsigned)lane & 31u);
+	// First try without any per-token checks and with the serial part cut down to the state chain
+	// (b,o) -> (b + 2z + o + 2, max(o + z - 2, 0)): it only needs the zero count at b (one v_readlane) and
+	// leaves each token's order in the lane of its offset.  The lanes then work out their tokens' run
+	// lengths together and a DPP reduction adds them up.  Offsets only grow, so the loops end whatever
+	// the bits are; a token longer than the 32-bit window, a run the 32-bit sum cannot hold or an
+	// overshoot of the segment (once per segment) just sends the chunk to the checked loop below.
+	{
+		const int zA = winA ? __builtin_ctz(winA) : 32, zB = winB ? __builtin_ctz(winB) : 32;
+		int ordA = -1, ordB = -1, offf = off, of = o, worst = 0;
+		while (offf < 64) {
+			const int z = __builtin_amdgcn_readlane(zA, offf);
+			const int top = of + z;
+			worst = max(worst, z + top);
+			ordA = lane == offf ? of : ordA;
+			offf += z + top + 2;
+			of = max(top, 2) - 2;
+		}
+		while (offf < 128) {
+			const int z = __builtin_amdgcn_readlane(zB, offf - 64);
+			const int top = of + z;
+			worst = max(worst, z + top);
+			ordB = lane == offf - 64 ? of : ordB;
+			offf += z + top + 2;
+			of = max(top, 2) - 2;
+		}
+		if (worst <= 30) {
+			constexpr unsigned CAP = 1u << 24;   // 128 tokens of at most this many symbols cannot overflow
+			auto cost = [&](unsigned win, int z, int ord) -> unsigned {
+				const int top = ord + z;
+				const unsigned run = ((win >> ((z + 1) & 31)) & ((1u << (top & 31)) - 1u)) + (1u << (top & 31)) - (1u << (ord & 31));
+				return ord < 0 ? 0u : min(run + 1u, CAP);
+			};
+			const unsigned cA = cost(winA, zA, ordA), cB = cost(winB, zB, ordB);
+			const unsigned long long visA = __ballot(ordA >= 0), visB = __ballot(ordB >= 0);
+			const bool capped = __ballot(cA == CAP || cB == CAP) != 0;
+			int v = (int)(cA + cB);
+			v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+			v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+			v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+			v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror: every lane has its row's sum
+			const unsigned symf = (unsigned)(__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+				__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+			if (!capped && symf <= need) {
+				ChunkScan r = { (unsigned)(__builtin_popcountll(visA) + __builtin_popcountll(visB)), symf, offf, of };
+				return r;
+			}
+		}
+	}
 	unsigned tok = 0, left = need;   // left = symbols the segment still takes
 	// branch-free token step (single-exit loops keep the scalar code tight); false = stop at this token
 	auto token = [&](unsigned w32) -> bool {
