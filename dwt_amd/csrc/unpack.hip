@@ -740,32 +740,34 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 		// Symbol positions only grow: gather the bits of one bitmap word before touching memory.  The
 		// words strictly inside this piece's symbol range belong to it alone (neighbouring pieces and the
 		// walker's own tokens can only share its first and last word), so only those two need atomics.
-		long cur = -1;
-		unsigned acc = 0;
+		// A piece stays inside its segment (< 2^28 symbols): positions are 32-bit offsets from its first word.
+		unsigned *wp = sym + (pos >> 4);
+		unsigned rp = (unsigned)(pos & 15);
+		unsigned cur = 0xffffffffu, acc = 0;
 		bool first = true;
 		chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
 			if (!left)
 				return false;
-			pos += run;
-			const long wi = (long)(pos >> 4);
+			rp += run;
+			const unsigned wi = rp >> 4;
 			if (wi != cur) {
 				if (acc) {
 					if (first)
-						atomicOr(sym + cur, acc);
+						atomicOr(wp + cur, acc);
 					else
-						sym[cur] = acc;
+						wp[cur] = acc;
 					first = false;
 				}
 				cur = wi;
 				acc = 0;
 			}
-			acc |= (1u | (neg << 1)) << ((pos & 15) * 2);
-			++pos;
+			acc |= (1u | (neg << 1)) << ((rp & 15u) * 2u);
+			++rp;
 			--left;
 			return true;
 		});
 		if (acc)
-			atomicOr(sym + cur, acc);
+			atomicOr(wp + cur, acc);
 	};
 	const bool mine = chunk < w.nch[img] && chunk >= 1;
 	// Most workgroups lie inside one long hop: its record is then the same for every thread and is
