@@ -194,6 +194,44 @@ def main():
     samples = B * W * H * C
     achieved = LIFT_BYTES_PER_SAMPLE * samples / (lift_ms * 1e-3) / 1e9
 
+    # ---- the entropy stage on its own (4 B coefficient + stream bytes per sample and direction) --
+    lin = ctx.linearization(pyr)
+    del back
+    cstreams = torch.empty((B, stride), dtype=torch.uint8, device=dev)
+    cinfo = torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev)
+    hinfo = (dwt_amd.DecodeInfo * B)()
+
+    def coder_enc():
+        rc = ctx.lib.dwtx_encode_planes(ctx.h, lin.data_ptr(), W, H, C, B, 0, cstreams.data_ptr(), stride, cinfo.data_ptr())
+        assert rc == 0, rc
+
+    coder_enc()
+    clens = ctx.stream_lengths(cinfo)
+    lin_out = torch.empty_like(lin)
+
+    def coder_dec():
+        rc = ctx.lib.dwtx_decode_planes(ctx.h, lin_out.data_ptr(), cstreams.data_ptr(), stride, clens.data_ptr(), W, H, C, B, -1,
+                                        ctypes.cast(hinfo, ctypes.c_void_p))
+        assert rc == 0, rc
+
+    coder_dec()
+    torch.cuda.synchronize()
+    c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    c0.record()
+    coder_enc()
+    c1.record()
+    coder_dec()
+    c2.record()
+    torch.cuda.synchronize()
+    coder_ok = bool(torch.equal(lin_out, lin))
+    coder_bytes = 4 * samples + int(clens.sum().item())
+    coder = {"what": "dwtx_encode_planes / dwtx_decode_planes alone on the same frames (linearised coefficients <-> streams)",
+             "algorithmic_bytes_per_step": coder_bytes, "coefficients_roundtrip": coder_ok}
+    for name, ms in (("encode", c0.elapsed_time(c1)), ("decode", c1.elapsed_time(c2))):
+        coder[name] = {"ms_per_step": round(ms, 3), "achieved_GBs": round(coder_bytes / (ms * 1e-3) / 1e9, 1),
+                       "frac_of_hbm_peak": round(coder_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del lin, lin_out, cstreams
+
     # ---- stage breakdown (one extra untimed pass with events) ----------------------
     def timed(fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -239,6 +277,7 @@ def main():
                           "lifting_roundtrip": lift_ok},
             "bytes_per_frame": int(sum(lens_host) / len(lens_host)),
             "stage_ms_per_step": {"encode": round(enc_ms, 3), "decode": round(dec_ms, 3)},
+            "coder": coder,
             "roofline": {
                 "kernel": "k_fwd_level + k_inv_level (all levels, forward+inverse CDF 5/3)",
                 "bound": "hbm",
