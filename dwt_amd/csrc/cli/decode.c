@@ -14,7 +14,7 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	const char *fname = std_name(argv[1], "/dev/stdin");
-	FILE *f = fopen(fname, "rb");
+	FILE *f = open_stream(argv[1], fname, 0);
 	if (!f) {
 		fprintf(stderr, "could not open \"%s\" file to read\n", fname);   /* bytes.h:31 */
 		return 1;

@@ -37,7 +37,7 @@ int main(int argc, char **argv)
 	}
 	/* bytes.h:40-57: the sink is opened after the transform, before the first byte */
 	const char *fname = std_name(argv[2], "/dev/stdout");
-	FILE *f = fopen(fname, "wb");
+	FILE *f = open_stream(argv[2], fname, 1);
 	if (!f) {
 		fprintf(stderr, "could not open \"%s\" file to write\n", fname);
 		return 1;

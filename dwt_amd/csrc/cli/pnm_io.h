@@ -8,12 +8,29 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 
 static const char *std_name(const char *name, const char *fallback)
 {
 	/* bytes.h:26-28,42-44 / pnm.h:16-18,93-95: exactly "-" selects the standard stream */
 	return (name[0] == '-' && !name[1]) ? fallback : name;
+}
+
+/* "-" means the process's own standard stream (bytes.h:26-28,42-44, pnm.h:16-18,93-95 open
+ * /dev/stdin and /dev/stdout by path; a duplicate of the descriptor is the same file without the
+ * path lookup, which some sandboxes refuse for pipes). */
+static FILE *open_stream(const char *name, const char *fname, int writing)
+{
+	if (fname != name) {
+		int fd = dup(writing ? 1 : 0);
+		FILE *f = fd >= 0 ? fdopen(fd, writing ? "wb" : "rb") : 0;
+		if (f)
+			return f;
+		if (fd >= 0)
+			close(fd);
+	}
+	return fopen(fname, writing ? "wb" : "rb");
 }
 
 static uint8_t *read_all(FILE *f, size_t *len)
@@ -38,7 +55,7 @@ static uint8_t *read_all(FILE *f, size_t *len)
 static uint8_t *pnm_read(const char *name, int *W, int *H, int *C)
 {
 	const char *fname = std_name(name, "/dev/stdin");
-	FILE *f = fopen(fname, "rb");
+	FILE *f = open_stream(name, fname, 0);
 	if (!f) {
 		fprintf(stderr, "could not open \"%s\" file to read.\n", fname);
 		return 0;
@@ -104,7 +121,7 @@ eof:
 static int pnm_write(const char *name, const uint8_t *pix, int W, int H, int C)
 {
 	const char *fname = std_name(name, "/dev/stdout");
-	FILE *f = fopen(fname, "wb");
+	FILE *f = open_stream(name, fname, 1);
 	if (!f) {
 		fprintf(stderr, "could not open \"%s\" file to write.\n", fname);
 		return 0;
