@@ -74,8 +74,8 @@ extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 			(void)hipFree(c->scratch[i]);
 	if (c->have_aux) {
 		(void)hipStreamDestroy(c->aux);
-		(void)hipEventDestroy(c->ev[0]);
-		(void)hipEventDestroy(c->ev[1]);
+		for (int i = 0; i < 4; ++i)
+			(void)hipEventDestroy(c->ev[i]);
 	}
 	if (c->have_copy) {
 		(void)hipStreamDestroy(c->copy);

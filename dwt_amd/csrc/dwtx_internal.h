@@ -18,7 +18,7 @@ struct dwtx_ctx {
 	size_t scratch_bytes[DWTX_SCRATCH_SLOTS];
 	dwtx_linplan *plans;   // per-geometry Hilbert block tables (linearize.hip)
 	hipStream_t aux;       // second stream: half of a decode batch runs here so that one half's serial
-	hipEvent_t ev[2];      // token walk overlaps the other half's parallel kernels (unpack.hip)
+	hipEvent_t ev[4];      // token walk overlaps the other half's parallel kernels (unpack.hip); [2],[3]: bitmap clear
 	bool have_aux;
 	hipStream_t copy;      // host-buffer wrappers: transfers of one part of a batch overlap the kernels of another (codec.hip)
 	hipEvent_t cev[6];

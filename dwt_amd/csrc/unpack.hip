@@ -1460,7 +1460,18 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		w.nch = (int *)(chunks + o_nc);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
-		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)n * w.BW, ctx->stream));
+		// The symbol bitmap (the one big clear, ~64 MB per 4096x4096 plane) is only needed by the token walk:
+		// it is cleared on the second stream while the chunk tables are built on the first.
+		if (!ctx->have_aux) {
+			DWTX_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+			for (int i = 0; i < 4; ++i)
+				DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+			ctx->have_aux = true;
+		}
+		DWTX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));            // earlier work on the main stream may still read the bitmap
+		DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[2], 0));
+		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)n * w.BW, ctx->aux));
+		DWTX_HIP(hipEventRecord(ctx->ev[3], ctx->aux));
 	}
 	hipStream_t s = ctx->stream;
 	// decode.c:177-179 zeroes everything; here the rings are written exactly once by k_apply_all, so only
@@ -1529,6 +1540,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	auto walk = [&](hipStream_t st, int i0, int cnt) -> int {
 		const DWork h = slice(i0);
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
+		DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));   // the bitmap is clear
 		hipLaunchKernelGGL(k_tokenize, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
 			lin + (size_t)i0 * C * g.lin_stride, cnt);
 		hipLaunchKernelGGL(k_hopbits, dim3((unsigned)((w.NCH + 255) / 256), cnt), dim3(256), 0, st, h, str, (long)stream_stride);
@@ -1563,12 +1575,6 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	// The token walk is one wave per image and leaves the chip idle: run the two halves of the batch
 	// on two streams, the second one half a pipeline behind, so that each half's walk overlaps the
 	// other half's parallel kernels.
-	if (!ctx->have_aux) {
-		DWTX_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-		DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[0], hipEventDisableTiming));
-		DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[1], hipEventDisableTiming));
-		ctx->have_aux = true;
-	}
 	const int na = n / 2;
 	if ((rc = pre(s, 0, na)))
 		return rc;
