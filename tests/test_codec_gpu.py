@@ -47,6 +47,26 @@ def test_config_d_16384_rgb_truncated_to_1mib(ctx):
     assert h.hexdigest() == rec["dec_sha256"]
 
 
+def test_config_d_16384_rgb_whole_stream(ctx):
+    """The same 805 M-sample frame without a capacity: 3 Gbit of stream (bit positions beyond 2^31), its first
+    MiB is the reference's CAPACITY=1 MiB output (truncation yields a prefix), and it decodes
+    back to the pixels."""
+    import torch
+
+    rec = G["c16384x16384_cap1MiB"]
+    W, H, Cn = rec["W"], rec["H"], rec["C"]
+    pix = ctx.synth_pixels(1, H, W, Cn, seed0=0, kind=0)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    assert int(lens[0]) * 8 > 1 << 31
+    assert sha(streams[0, : rec["capacity"]].cpu().numpy().tobytes()) == rec["dwt_sha256"]
+    out, infos = ctx.decode_device(streams, lens, W, H, Cn)
+    assert infos[0].status == 0 and not infos[0].truncated
+    assert torch.equal(out.view(1, H, W, Cn), pix)
+    del out, streams, pix
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", sorted(k for k in G if not G[k].get("heavy")))
 def test_goldens_from_the_real_reference(ctx, name):
     rec = G[name]
