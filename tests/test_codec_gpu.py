@@ -67,6 +67,22 @@ def test_config_d_16384_rgb_whole_stream(ctx):
     torch.cuda.empty_cache()
 
 
+def test_stream_longer_than_2_to_32_bits(ctx):
+    """Uniform noise at 16384x16384 RGB costs ~9 bit per sample: 7 Gbit of stream, every bit offset is 64-bit."""
+    import torch
+
+    W = H = 16384
+    pix = ctx.synth_pixels(1, H, W, 3, seed0=3, kind=1)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    assert int(lens[0]) * 8 > 1 << 32
+    out, infos = ctx.decode_device(streams, lens, W, H, 3)
+    assert infos[0].status == 0 and not infos[0].truncated
+    assert torch.equal(out.view(1, H, W, 3), pix)
+    del out, streams, pix
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", sorted(k for k in G if not G[k].get("heavy")))
 def test_goldens_from_the_real_reference(ctx, name):
     rec = G[name]
