@@ -99,7 +99,8 @@ def test_goldens_from_the_real_reference(ctx, name):
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 1), (9, 8, 3), (77, 131, 3), (300, 17, 1), (255, 257, 3), (33, 1000, 1),
-                                   (700, 1000, 3), (1025, 2047, 1), (1030, 1548, 3)])
+                                   (700, 1000, 3), (1025, 2047, 1), (1030, 1548, 3), (8, 4096, 1), (4096, 8, 3),
+                                   (9, 3000, 3)])   # (the oracle walks the whole pow2 square: much longer sides take minutes)
 def test_roundtrip_and_oracle_bytes(ctx, shape):
     H, W, Cn = shape
     for kind in (0, 1):
