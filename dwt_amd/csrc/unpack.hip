@@ -6,28 +6,36 @@
 // raw bits whose count depends on what earlier planes made significant).  The
 // work is split so that only the irreducible part stays serial:
 //
-//   k_tokenize  one lane per image: walks header, root image, plane counts and
-//               the segment schedule, parsing VLI tokens with a register
-//               look-ahead FIFO.  It touches no coefficient: per-(channel,
-//               level) counters of not-yet-significant coefficients tell it how
-//               many symbols each segment holds.  Output: for every pass-1
-//               symbol that is a one, two bits in `symbits` (one flag, sign)
-//               at (segment symbol base + symbol index); per
-//               segment the stream offset of its refinement block.  Truncated
-//               streams simply stop here; what was parsed stays valid
-//               (decode.c:204-205).
-//   k_spec/k_link/k_scan_*/k_breaks  speculative 128-bit chunk parse that lets the
+//   k_nch       chunks of every stream that hold bytes (the tables below are laid
+//               out for the stream stride but worked on only that far).
+//   k_spec/k_link_*/k_scan_*/k_breaks  speculative 128-bit chunk parse that lets the
 //               walker jump over stitched stretches of the stream (see below).
-//   k_hopbits   sets the symbol bits of everything the walker jumped over.
+//   k_tokenize  one wave per image (all lanes on the same uniform values): walks
+//               header, root image, plane counts and the segment schedule.  It
+//               touches no coefficient: per-(channel, level) counters of
+//               not-yet-significant coefficients tell it how many symbols each
+//               segment holds.  On a stitched path it hops over whole runs of
+//               chunks (64-way search in the prefix sums); otherwise it parses one
+//               chunk at a time with chunk_scan, counting only.  Output: hop
+//               records, per segment the stream offset of its refinement block,
+//               and for the few tokens it reads bit by bit two bits in `symbits`
+//               (one flag, sign) at (segment symbol base + symbol index).
+//               Truncated streams simply stop here; what was parsed stays valid
+//               (decode.c:204-205).
+//   k_hopbits   re-parses every chunk (piece) the walker accounted for and sets
+//               its symbol bits.
 //   k_rank + k_count  per plane, descending, on per-tile COUNTS only: first pass-1
 //               symbol index of every 1024-coefficient tile (exclusive scan of the
 //               tiles' insignificant counts) and the ones each tile gains (popcount
-//               of its slice of `symbits`).
+//               of its slice of `symbits`; also flags planes that turn coefficients
+//               of the tile on).
 //   k_apply_all one wave per tile, all planes in registers: an insignificant
 //               coefficient is pass-1 symbol #rank -> bits from `symbits`; a
 //               significant one is refinement bit #(index - rank) -> read straight
 //               from the stream.  Written once, in two's complement
 //               (decode.c:102-117).
+// Batches run as two halves on two streams (the second also clears `symbits`
+// while the first builds its tables); see dwtx_decode_planes_ex.
 #include "dwtx_internal.h"
 
 #include <stdlib.h>
