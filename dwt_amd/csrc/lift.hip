@@ -2,7 +2,8 @@
 // integer lifting transform (forward: encode.c:16-30 over cdf53.h:9-34; inverse:
 // decode.c:16-30 over cdf53.h:36-61) as streaming gfx950 kernels.
 //
-// Layout: planar int32, plane p = image*C + channel, dense rows.
+// Layout: planar int32, plane p = image*C + channel, dense rows; the finest level can
+// also read / write 8-bit pixels directly (gray or interleaved RGB with YCoCg-R fused).
 //
 // Kernel shape (one level, both directions): a 64-lane wave owns 64 adjacent
 // column PAIRS (x = 2k, 2k+1) and walks down a strip of row pairs.  The

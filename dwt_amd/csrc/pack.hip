@@ -19,19 +19,22 @@
 //   k_entries_* an "entry" is (segment, tile).  Symbol counts per
 //             entry from the histograms, exclusive scans -> first token slot
 //             and refinement rank of every entry.
-//   k_tokens  one wave per entry: classify 64 coefficients per row at the
-//             entry's plane; every significant one becomes a token
-//             (zero run since the previous one in this tile, sign).
+//   k_tokens  one wave per tile, all planes: classify 64 coefficients per row at
+//             each plane that codes the tile; every newly significant one
+//             becomes a token (zero run since the previous one in this tile,
+//             sign).
 //   k_carry_* batch-wide segmented scan of pending zero runs across entries,
 //             segment ends (phantom terminators, rle.h:79-89) and the final
 //             flush; patches the first token of each entry.
-//   k_lut/k_chain*/k_orders  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0)
-//             is a scan over monotone maps on 32 states: lanes act as the 32
-//             start states, chunk maps are composed hierarchically.
+//   k_orders_fast  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0) per 64-token
+//             group from the chains started at order 0 and 31 (they almost
+//             always meet); k_lut/k_chain*/k_orders redo flagged images exactly
+//             as a scan over monotone maps on 32 states.
 //   k_bitscan per image: exclusive scan of chunk bit totals -> bit offsets.
-//   k_emit    one lane per 64 tokens: sequential LSB-first bit writer over the
-//             lane's contiguous bit range, words merged with atomicOr.
-//   k_refine  one wave per entry: refinement bits, compacted through LDS.
+//   k_clear_stream  zeroes the words the stream will occupy.
+//   k_emit    one lane per four tokens: their codes glued into one bit string,
+//             a wave's strings merged in LDS, words merged with atomicOr.
+//   k_refine  one wave per tile, all planes: refinement bits, compacted through LDS.
 #include "dwtx_internal.h"
 
 #include <stdlib.h>
