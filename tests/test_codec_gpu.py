@@ -261,3 +261,24 @@ def test_host_batches_pipeline_in_parts(ctx, monkeypatch):
     for i in range(n):
         want = orc.decode(streams[i])
         assert outs[i].shape == want.shape and (outs[i] == want).all()
+
+
+def test_corrupted_streams_decode_like_the_oracle(ctx):
+    """Bit flips, byte garbage and junk tails after a valid header: whatever the reference's decoder makes of
+    such a stream (early stop, resolution drop, rle_get_bit refusing a run, ...) the GPU path makes too."""
+    from test_oracle import corrupted_blobs   # the same blobs the oracle is pinned on against the real reference
+
+    pix = orc.synth(96, 80, 3, 12, 0)
+    good, _ = ctx.encode(pix)
+    blobs = corrupted_blobs(good)
+    for blob in blobs:
+        want = orc.decode(blob)
+        got = ctx.decode(blob)
+        if want is None:
+            assert got is None
+        else:
+            assert got is not None and got.shape == want.shape and (got == want).all()
+    outs = ctx.decode(blobs[:12])   # and as one batch (both decoder halves)
+    for blob, got in zip(blobs[:12], outs):
+        want = orc.decode(blob)
+        assert (want is None and got is None) or (got.shape == want.shape and (got == want).all())

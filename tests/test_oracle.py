@@ -140,3 +140,46 @@ def test_against_reference_binaries(tmp_path, shape):
                 assert back is None
             else:
                 assert (orc.read_pnm(dec) == back).all() and orc.read_pnm(dec).shape == back.shape
+
+
+def corrupted_blobs(good, n=40, seed=7):
+    """The corruptions tests/test_codec_gpu.py feeds the GPU decoder (bit flips, garbage runs, junk tails)."""
+    rng = np.random.default_rng(seed)
+    blobs = []
+    for case in range(n):
+        b = bytearray(good)
+        kind = case % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(6, len(b)))
+                b[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            i = int(rng.integers(6, len(b) - 40))
+            b[i:i + 32] = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        elif kind == 2:
+            i = int(rng.integers(40, len(b)))
+            b[i:] = bytes(rng.integers(0, 256, len(b) - i, dtype=np.uint8))
+        else:
+            i = int(rng.integers(40, len(b)))
+            b[i:] = bytes([0 if case % 8 == 3 else 255]) * (len(b) - i)
+        blobs.append(bytes(b))
+    return blobs
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_corrupted_streams_against_reference_binary(tmp_path):
+    """Pins the restatement's error paths (rle.h:58-61,95-101, vli.h, decode.c:204-239) on damaged streams."""
+    pix = orc.synth(96, 80, 3, 12, 0)
+    good, _ = orc.encode(pix)
+    dwt, dec = str(tmp_path / "c.dwt"), str(tmp_path / "c.pnm")
+    for blob in corrupted_blobs(good):
+        open(dwt, "wb").write(blob)
+        if os.path.exists(dec):
+            os.remove(dec)
+        r = subprocess.run([os.path.join(orc.REF_DIR, "decode"), dwt, dec], capture_output=True, timeout=120)
+        back = orc.decode(blob)
+        if r.returncode:
+            assert back is None
+        else:
+            ref = orc.read_pnm(dec)
+            assert back is not None and ref.shape == back.shape and (ref == back).all()
