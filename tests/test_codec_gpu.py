@@ -268,16 +268,17 @@ def test_corrupted_streams_decode_like_the_oracle(ctx):
     such a stream (early stop, resolution drop, rle_get_bit refusing a run, ...) the GPU path makes too."""
     from test_oracle import corrupted_blobs   # the same blobs the oracle is pinned on against the real reference
 
-    pix = orc.synth(96, 80, 3, 12, 0)
-    good, _ = ctx.encode(pix)
-    blobs = corrupted_blobs(good)
-    for blob in blobs:
-        want = orc.decode(blob)
-        got = ctx.decode(blob)
-        if want is None:
-            assert got is None
-        else:
-            assert got is not None and got.shape == want.shape and (got == want).all()
+    for (W, H, Cn, seed, bseed) in ((96, 80, 3, 12, 7), (131, 77, 1, 5, 100), (64, 64, 3, 9, 101), (200, 117, 1, 3, 102)):
+        pix = orc.synth(W, H, Cn, seed, 0)
+        good, _ = ctx.encode(pix)
+        blobs = corrupted_blobs(good, 40, bseed)
+        for blob in blobs:
+            want = orc.decode(blob)
+            got = ctx.decode(blob)
+            if want is None:
+                assert got is None
+            else:
+                assert got is not None and got.shape == want.shape and (got == want).all()
     outs = ctx.decode(blobs[:12])   # and as one batch (both decoder halves)
     for blob, got in zip(blobs[:12], outs):
         want = orc.decode(blob)
