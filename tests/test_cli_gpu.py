@@ -148,3 +148,44 @@ def test_encode_cli_against_reference_goldens(tmp_path, name):
     back = orc.read_pnm(pnm)
     assert back.shape[:2] == (rec["dec_H"], rec["dec_W"])
     assert hashlib.sha256(back.tobytes()).hexdigest() == rec["dec_sha256"]
+
+
+def _odd_pnms():
+    px = bytes(range(256)) * 3
+    body5, body6 = px[:12 * 9], px[:12 * 9 * 3]
+    return {
+        "plain_p5": b"P5 12 9 255\n" + body5,
+        "plain_p6": b"P6\n12 9\n255\n" + body6,
+        "comment_lines": b"P5\n# made by hand\n12 9\n# another\n255\n" + body5,
+        "tabs_and_spaces": b"P6 \t 12   9\t255\n" + body6,
+        "crlf_after_maxval": b"P5 12 9 255\r\n" + body5,
+        "maxval_65535": b"P5 12 9 65535\n" + body5 * 2,
+        "maxval_100": b"P5 12 9 100\n" + body5,
+        "p4_bitmap": b"P4 16 9\n" + bytes(18),
+        "p3_ascii": b"P3 2 2 255\n1 2 3 4 5 6 7 8 9 10 11 12\n",
+        "short_pixels": b"P6 12 9 255\n" + body6[:100],
+        "extra_tail": b"P5 12 9 255\n" + body5 + b"trailing junk",
+        "too_small": b"P5 7 20 255\n" + bytes(140),
+        "zero_width": b"P5 0 9 255\n",
+        "no_maxval": b"P5 12 9\n",
+        "empty": b"",
+        "just_magic": b"P5",
+        "negative": b"P5 -12 9 255\n" + body5,
+        "huge_width": b"P5 70000 9 255\n" + body5,
+    }
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", sorted(_odd_pnms()))
+def test_pnm_reading_matches_the_reference_binary(tmp_path, name):
+    """read_pnm's accept/reject rules and messages (pnm.h:14-90): bin/encode and the reference's own encode
+    on the same odd PNM files — exit code, stderr and bytes."""
+    (tmp_path / "in.pnm").write_bytes(_odd_pnms()[name])
+    mine = subprocess.run([ENC, "in.pnm", "mine.dwt"], cwd=tmp_path, capture_output=True, timeout=300)
+    ref = subprocess.run([os.path.join(orc.REF_DIR, "encode"), "in.pnm", "ref.dwt"], cwd=tmp_path, capture_output=True, timeout=300)
+    # on two of these ("EOF while reading" with nothing after the header) the reference prints its message and
+    # then crashes with SIGSEGV; the drop-in prints the same message and exits 1
+    assert mine.returncode == (1 if ref.returncode < 0 else ref.returncode), (mine.stderr, ref.stderr)
+    assert mine.stderr == ref.stderr
+    if ref.returncode == 0:
+        assert (tmp_path / "mine.dwt").read_bytes() == (tmp_path / "ref.dwt").read_bytes()
