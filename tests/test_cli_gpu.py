@@ -189,3 +189,36 @@ def test_pnm_reading_matches_the_reference_binary(tmp_path, name):
     assert mine.stderr == ref.stderr
     if ref.returncode == 0:
         assert (tmp_path / "mine.dwt").read_bytes() == (tmp_path / "ref.dwt").read_bytes()
+
+
+def _odd_dwts():
+    good = open(os.path.join(orc.GOLDEN, "c37x53.dwt"), "rb").read()
+    return {
+        "good": good,
+        "bad_magic": b"X6" + good[2:],
+        "bad_channel_magic": b"W7" + good[2:],
+        "lowercase_magic": b"w6" + good[2:],
+        "p5_magic_on_rgb_stream": b"W5" + good[2:],
+        "width_7": b"W6" + bytes([6, 0]) + good[4:],
+        "height_3": good[:4] + bytes([2, 0]) + good[6:],
+        "other_width": good[:2] + bytes([99, 0]) + good[4:],
+        "empty": b"",
+        "one_byte": b"W",
+        "header_only": good[:6],
+        "zeros_after_header": good[:6] + bytes(400),
+        "ones_after_header": good[:6] + b"\xff" * 400,
+    }
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", sorted(_odd_dwts()))
+def test_dwt_header_handling_matches_the_reference_binary(tmp_path, name):
+    """decode.c:142-186 on damaged or foreign headers: bin/decode and the reference's own decode — exit
+    code, stderr and picture."""
+    (tmp_path / "in.dwt").write_bytes(_odd_dwts()[name])
+    mine = subprocess.run([DEC, "in.dwt", "mine.pnm"], cwd=tmp_path, capture_output=True, timeout=300)
+    ref = subprocess.run([os.path.join(orc.REF_DIR, "decode"), "in.dwt", "ref.pnm"], cwd=tmp_path, capture_output=True, timeout=300)
+    assert mine.returncode == (1 if ref.returncode < 0 else ref.returncode), (mine.stderr, ref.stderr)
+    assert mine.stderr == ref.stderr
+    if ref.returncode == 0:
+        assert (tmp_path / "mine.pnm").read_bytes() == (tmp_path / "ref.pnm").read_bytes()
