@@ -198,7 +198,7 @@ extern "C" int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *pix, int W, int 
 				hipMemcpyDeviceToHost, cs);
 			if (stats) {
 				dwtx_stats &st = stats[i0 + i];
-				st.meta_bits = 48;                                   // encode.c:175
+				st.meta_bits = (int)hi[i].meta_bits;                 // encode.c:175
 				st.root_bits = (int)hi[i].root_bits;                 // encode.c:179
 				st.total_bits = (int)hi[i].total_bits;               // encode.c:226 (int there too)
 				st.kib = (int)((hi[i].nbytes + 512) / 1024);         // encode.c:228

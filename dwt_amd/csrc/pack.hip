@@ -69,6 +69,8 @@ struct ImgInfo {
 	int order0;            // VLI order after header + root + plane counts
 	unsigned hdr_bits;
 	unsigned root_bits;
+	unsigned meta_bits;
+	unsigned pad0;
 	unsigned long long total_bits;
 	unsigned long long nbytes;
 	int error;
@@ -199,7 +201,41 @@ struct HdrWriter {
 	int n;
 	long pos;
 	int order;
+	// What the reference's own counters would say if CAPACITY cut into this part of the stream: a refused
+	// byte makes write_bits()/put_vli() give up the field they are writing (bits.h:58-78, vli.h:67-84, the
+	// order then stays as it was) while encode_root() carries on with the next value (encode.c:97-110).
+	// Only the statistics lines need this; the bytes are the prefix of the unlimited stream either way.
+	long rc_cap, rc_len;
+	int rc_n, rc_order;
+	__device__ bool rc_bits(int nb)   // false: a byte was refused
+	{
+		if (nb <= 0)
+			return true;
+		rc_n += nb;
+		while (rc_n >= 8) {
+			if (rc_cap > 0 && rc_len >= rc_cap) {
+				rc_n = 0;
+				return false;
+			}
+			++rc_len;
+			rc_n -= 8;
+		}
+		return true;
+	}
+	__device__ void rc_vli(unsigned v)
+	{
+		const int top = vli_top(rc_order, v);
+		if (!rc_bits(top - rc_order) || !rc_bits(1) || !rc_bits(top))
+			return;
+		rc_order = vli_next(top);
+	}
+	__device__ unsigned rc_count() const { return (unsigned)(rc_len * 8 + rc_n); }
 	__device__ void put(unsigned v, int nb)
+	{
+		rc_bits(nb);
+		put_raw(v, nb);
+	}
+	__device__ void put_raw(unsigned v, int nb)
 	{
 		if (nb <= 0)
 			return;
@@ -215,16 +251,17 @@ struct HdrWriter {
 	}
 	__device__ void vli(unsigned v)
 	{
+		rc_vli(v);
 		const int top = vli_top(order, v);
-		put(0, top - order);
-		put(1, 1);
-		put(v + (1u << order) - (1u << top), top);
+		put_raw(0, top - order);
+		put_raw(1, 1);
+		put_raw(v + (1u << order) - (1u << top), top);
 		order = vli_next(top);
 	}
 	__device__ unsigned bits() const { return (unsigned)(pos * 32 + n); }
 };
 
-__global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words)
+__global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words, long capacity)
 {
 	if (threadIdx.x)
 		return;
@@ -247,11 +284,16 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 	hw.n = 0;
 	hw.pos = 0;
 	hw.order = 0;
+	hw.rc_cap = capacity;
+	hw.rc_len = 0;
+	hw.rc_n = 0;
+	hw.rc_order = 0;
 	// encode.c:169-172 header bytes
 	hw.put('W', 8);
 	hw.put(g.C == 3 ? '6' : '5', 8);
 	hw.put((unsigned)(g.W - 1) & 0xffffu, 16);
 	hw.put((unsigned)(g.H - 1) & 0xffffu, 16);
+	I.meta_bits = hw.rc_count();   // encode.c:175-176
 	// encode.c:97-110 root image per channel
 	for (int c = 0; c < g.C; ++c) {
 		const int *r = lin + (long)(img * g.C + c) * g.total;
@@ -271,7 +313,7 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 					hw.put(v < 0, 1);
 			}
 	}
-	I.root_bits = hw.bits() - 48;
+	I.root_bits = hw.rc_count() - I.meta_bits;   // encode.c:179-180
 	for (int c = 0; c < g.C; ++c)   // encode.c:181-182
 		hw.vli((unsigned)planes[c]);
 	I.hdr_bits = hw.bits();
@@ -1534,7 +1576,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	// cleared by k_clear_stream once its length is known
 
 	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
-	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words);
+	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words, capacity);
 	hipLaunchKernelGGL(k_entries_count, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, g, w);
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);

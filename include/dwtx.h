@@ -71,7 +71,9 @@ typedef struct dwtx_stream_info {
 	unsigned tokens;               /* VLI token slots (incl. void ones) */
 	int order0;                    /* VLI order after header, root image and plane counts */
 	unsigned hdr_bits;             /* 48 header bits + root image + plane counts */
-	unsigned root_bits;            /* encode.c:179-180 */
+	unsigned root_bits;            /* encode.c:179-180, as the reference counts it (CAPACITY can cut into the root image) */
+	unsigned meta_bits;            /* encode.c:175-176: 48 unless CAPACITY < 6 */
+	unsigned reserved0;
 	unsigned long long total_bits; /* encode.c:226: bit count before padding (8*capacity when truncated) */
 	unsigned long long nbytes;     /* bytes of the .dwt stream: min(capacity, ceil(total_bits/8)) */
 	int error;                     /* non-zero: unsupported data (more than 16 bit planes) */

@@ -222,3 +222,22 @@ def test_dwt_header_handling_matches_the_reference_binary(tmp_path, name):
     assert mine.stderr == ref.stderr
     if ref.returncode == 0:
         assert (tmp_path / "mine.pnm").read_bytes() == (tmp_path / "ref.pnm").read_bytes()
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("arg", ["0", "-5", "abc", "12abc", "99999999999", "1", "47", "48", "600", " 300", "+300", "3e2", ""])
+def test_third_argument_parsing_matches_the_reference_binary(tmp_path, arg):
+    """CAPACITY (encode.c:150-152) and PIXELS (decode.c:165-171) go through atoi in the reference: same bytes,
+    exit codes and messages for odd spellings."""
+    pix = orc.synth(53, 37, 3, 4, 0)
+    orc.write_pnm(str(tmp_path / "in.pnm"), pix)
+    res = {}
+    for who, enc, dec in (("mine", ENC, DEC), ("ref", os.path.join(orc.REF_DIR, "encode"), os.path.join(orc.REF_DIR, "decode"))):
+        e = subprocess.run([enc, "in.pnm", who + ".dwt", arg], cwd=tmp_path, capture_output=True, timeout=300)
+        dwt = (tmp_path / (who + ".dwt")).read_bytes() if (tmp_path / (who + ".dwt")).exists() else None
+        full = subprocess.run([enc, "in.pnm", who + "_full.dwt"], cwd=tmp_path, capture_output=True, timeout=300)
+        assert full.returncode == 0
+        d = subprocess.run([dec, who + "_full.dwt", who + ".pnm", arg], cwd=tmp_path, capture_output=True, timeout=300)
+        pnm = (tmp_path / (who + ".pnm")).read_bytes() if (tmp_path / (who + ".pnm")).exists() else None
+        res[who] = (e.returncode, e.stderr, dwt, d.returncode, d.stderr, pnm)
+    assert res["mine"] == res["ref"]

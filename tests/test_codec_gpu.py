@@ -283,3 +283,16 @@ def test_corrupted_streams_decode_like_the_oracle(ctx):
     for blob, got in zip(blobs[:12], outs):
         want = orc.decode(blob)
         assert (want is None and got is None) or (got.shape == want.shape and (got == want).all())
+
+
+def test_statistics_when_capacity_cuts_into_header_or_root(ctx):
+    """encode.c:175-180,226-230 print the bit writer's own counters, and a refused byte makes the field being
+    written give up (bits.h:58-78): with CAPACITY below the header + root image the three numbers are not the
+    sizes of those parts.  Same numbers as the oracle (pinned on the reference in test_oracle.py)."""
+    for (W, H, Cn, seed) in ((53, 37, 3, 4), (64, 40, 1, 9)):
+        pix = orc.synth(W, H, Cn, seed, 0)
+        for cap in list(range(1, 20)) + [31, 47, 48, 60, 80, 85, 86, 87, 88, 90, 100, 120, 200]:
+            data, st = ctx.encode(pix, cap)
+            want, ost = orc.encode(pix, cap)
+            assert data == want, (W, H, Cn, cap)
+            assert (st.meta_bits, st.root_bits, st.total_bits, st.kib) == (ost.meta_bits, ost.root_bits, ost.total_bits, ost.kib), (W, H, Cn, cap)

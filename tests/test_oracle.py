@@ -183,3 +183,18 @@ def test_corrupted_streams_against_reference_binary(tmp_path):
         else:
             ref = orc.read_pnm(dec)
             assert back is not None and ref.shape == back.shape and (ref == back).all()
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_statistics_lines_under_tiny_capacities_against_reference_binary(tmp_path):
+    """With CAPACITY below header + root image the reference's three stderr numbers are its bit writer's
+    counters after fields were given up (bits.h:58-78); the restatement reproduces them."""
+    for (W, H, Cn, seed) in ((53, 37, 3, 4), (64, 40, 1, 9)):
+        pix = orc.synth(W, H, Cn, seed, 0)
+        orc.write_pnm(str(tmp_path / "in.pnm"), pix)
+        for cap in list(range(1, 20)) + [31, 47, 48, 60, 80, 85, 86, 87, 88, 90, 100, 120, 200]:
+            r = subprocess.run([os.path.join(orc.REF_DIR, "encode"), "in.pnm", "o.dwt", str(cap)], cwd=tmp_path, capture_output=True)
+            data, st = orc.encode(pix, cap)
+            assert (tmp_path / "o.dwt").read_bytes() == data
+            assert r.stderr.decode() == (f"{st.meta_bits} bits for meta data\n{st.root_bits} bits for root image\n"
+                                         f"{st.total_bits} bits ({st.kib} KiB) encoded\n")
