@@ -241,3 +241,18 @@ def test_third_argument_parsing_matches_the_reference_binary(tmp_path, arg):
         pnm = (tmp_path / (who + ".pnm")).read_bytes() if (tmp_path / (who + ".pnm")).exists() else None
         res[who] = (e.returncode, e.stderr, dwt, d.returncode, d.stderr, pnm)
     assert res["mine"] == res["ref"]
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("args", [[], ["a"], ["a", "b", "c", "d"], ["missing.pnm", "o"], ["in.pnm", "no/such/dir/o"],
+                                  ["in.pnm", "o", "10", "extra"]])
+def test_argument_errors_match_the_reference_binaries(tmp_path, args):
+    """Usage lines, unreadable inputs and unwritable outputs: same exit codes and messages (argv[0] aside)."""
+    orc.write_pnm(str(tmp_path / "in.pnm"), orc.synth(16, 16, 1, 0, 0))
+    (tmp_path / "in.dwt").write_bytes(open(os.path.join(orc.GOLDEN, "g8x8.dwt"), "rb").read())
+    for mine, ref in ((ENC, os.path.join(orc.REF_DIR, "encode")), (DEC, os.path.join(orc.REF_DIR, "decode"))):
+        a = [x.replace("in.pnm", "in.dwt") if mine == DEC else x for x in args]
+        m = subprocess.run([mine] + a, cwd=tmp_path, capture_output=True, timeout=300)
+        r = subprocess.run([ref] + a, cwd=tmp_path, capture_output=True, timeout=300)
+        assert m.returncode == (1 if r.returncode < 0 else r.returncode), (m.stderr, r.stderr)
+        assert m.stderr.replace(mine.encode(), b"PROG") == r.stderr.replace(ref.encode(), b"PROG")
