@@ -981,10 +981,12 @@ __global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
 // each token's order and bit offset.  Lane 0 only serves as the predecessor of
 // lane 1 (63 groups of output per wave).  If any pair of chains did not meet
 // the image is flagged and the exact hierarchical pass (k_lut ... k_orders)
-// redoes it.  Tokens go through LDS in tiles of 16 per group, so that several
+// redoes it.  Tokens go through LDS in tiles of QT per group, so that several
 // waves fit a SIMD.
 constexpr int FSUBS = 63;
-constexpr int QT = 16;
+constexpr int QT = 32;                    // tokens per group staged at a time (128-byte rows; 8 -> 1440, 16 -> 970, 32 -> 870, 64 -> 1380 us per 16 frames)
+constexpr int QLANES = QT / 4;            // lanes that move one group's QT tokens (four each)
+constexpr int QSUBS = 64 / QLANES;        // groups per wave instruction
 
 struct FastTile {
 	unsigned run[64][QT + 1];
@@ -1012,11 +1014,11 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 	const long S = wave * FSUBS - 1 + lane;          // this lane's 64-token group (lane 0: predecessor only)
 	const long tfirst = (wave * FSUBS - 1) * SUB;    // first token of the wave's window (-64 for wave 0)
 	// a lane moves four consecutive tokens of one group at a time: 16 bytes of runs, 4 bytes of flags
-	const int vsub = lane >> 2, q4 = (lane & 3) * 4;
+	const int vsub = lane / QLANES, q4 = (lane % QLANES) * 4;
 	auto load_tile = [&](int qt) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int sub = k * 16 + vsub;
+		for (int k = 0; k < 64 / QSUBS; ++k) {
+			const int sub = k * QSUBS + vsub;
 			const long t = tfirst + (long)sub * SUB + qt * QT + q4;   // multiple of 4, like every image's token base
 			uint4 r = make_uint4(0u, 0u, 0u, 0u);
 			unsigned f = F_VOID * 0x01010101u;
@@ -1114,8 +1116,8 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 		}
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int sub = k * 16 + vsub;
+		for (int k = 0; k < 64 / QSUBS; ++k) {
+			const int sub = k * QSUBS + vsub;
 			const long t = tfirst + (long)sub * SUB + qt * QT + q4;
 			if (sub < 1 || t >= T)
 				continue;
