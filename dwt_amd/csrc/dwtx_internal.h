@@ -63,6 +63,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
 	int (*done)(void *user, int first, int count), void *user);
 
+// The wave's lanes for which `pred` holds.  (HIP's __ballot() takes an int: the condition would be turned
+// into 0/1 in a register and compared again — two extra instructions per use in the ballot-heavy kernels.)
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // C truncating division by 2 and 4 on the device (cdf53.h:13,20 use `/`)
 __device__ __forceinline__ int tdiv2(int a) { return (a + (int)((unsigned)a >> 31)) >> 1; }
 __device__ __forceinline__ int tdiv4(int a) { return (a + ((a >> 31) & 3)) >> 2; }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 		if (full) {
 			slot[q] = i;
 		} else {
-			const unsigned long long mask = __ballot(ok[q]);
+			const unsigned long long mask = ballot64(ok[q]);
 			const int before = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 			if (lane == 0)
 				wcount[wv] = __builtin_popcountll(mask);

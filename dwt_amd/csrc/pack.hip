@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 		const int v = in ? src[i] : 0;
 		m[r] = in ? (unsigned)(v < 0 ? -v : v) : 0xffffffffu;   // out-of-ring lanes count nowhere
 		mx |= in ? m[r] : 0u;
-		valid += __builtin_popcountll(__ballot(in));
+		valid += __builtin_popcountll(ballot64(in));
 	}
 	for (int o = 32; o; o >>= 1)
 		mx |= __shfl_xor(mx, o);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 		int c = 0;
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r)
-			c += __builtin_popcountll(__ballot(m[r] < (1u << p)));
+			c += __builtin_popcountll(ballot64(m[r] < (1u << p)));
 		mine = lane == p ? c : mine;
 	}
 	if (lane < NCUM)
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 			const bool refine = (mag >> (p + 1)) != 0;
 			const bool one = in[r] && !refine && ((mag >> p) & 1u);
 			const bool zero = in[r] && !refine && !one;
-			const unsigned long long om = __ballot(one), zm = __ballot(zero);
+			const unsigned long long om = ballot64(one), zm = ballot64(zero);
 			if (om) {
 				const unsigned z = (unsigned)popc_below(zm), k = (unsigned)popc_below(om);
 				if (one)
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 			entry_known = true;
 		}
 		const bool resolve = valid && !exit_known && entry_known;
-		if (!__ballot(resolve))
+		if (!ballot64(resolve))
 			break;
 		int e = o;
 		for (int qt = 0; qt < SUB / QT; ++qt) {
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_orders_fast(Work w)
 			exit_known = true;
 		}
 	}
-	if (__ballot(lane >= 1 && valid && !entry_known)) {
+	if (ballot64(lane >= 1 && valid && !entry_known)) {
 		if (lane == 0)
 			atomicOr(w.slow + img, 1);
 		return;   // the exact pass takes the whole image
@@ -1211,10 +1211,10 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 	// group move up by its size (k_orders_fast / k_orders counted it for the groups after that)
 	const unsigned brk4 = f4 & (F_BREAK * 0x01010101u);
 	bool split = false;   // a refinement block lies between this lane's tokens
-	if (__ballot(brk4 != 0)) {
+	if (ballot64(brk4 != 0)) {
 #pragma unroll
 		for (int e = 0; e < EMIT_TOK; ++e) {
-			unsigned long long bm = __ballot((brk4 >> (8 * e)) & F_BREAK);
+			unsigned long long bm = ballot64(((brk4 >> (8 * e)) & F_BREAK) != 0);
 			while (bm) {
 				const int j = __builtin_ctzll(bm);
 				bm &= bm - 1;
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_refine(PackGeom g, const int *__restric
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
 			const bool refine = in[r] && (m[r] >> (p + 1)) != 0;
-			const unsigned long long rm = __ballot(refine);
+			const unsigned long long rm = ballot64(refine);
 			if (refine && ((m[r] >> p) & 1u)) {
 				const unsigned pos = (unsigned)shift + done + (unsigned)__builtin_popcountll(rm & below);
 				atomicOr(&st[pos >> 5], 1u << (pos & 31));

@@ -361,8 +361,8 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 				return ord < 0 ? 0u : min(run + 1u, CAP);
 			};
 			const unsigned cA = cost(winA, zA, ordA), cB = cost(winB, zB, ordB);
-			const unsigned long long visA = __ballot(ordA >= 0), visB = __ballot(ordB >= 0);
-			const bool capped = __ballot(cA == CAP || cB == CAP) != 0;
+			const unsigned long long visA = ballot64(ordA >= 0), visB = ballot64(ordB >= 0);
+			const bool capped = ballot64(cA == CAP || cB == CAP) != 0;
 			int v = (int)(cA + cB);
 			v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
 			v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
@@ -458,11 +458,11 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 {
 	const int lane = threadIdx.x & 63;
 	const int shard = (int)((ch >> 8) % LINK_SHARDS);
-	unsigned long long todo = __ballot(want);
+	unsigned long long todo = ballot64(want);
 	while (todo) {
 		const int leader = __builtin_ctzll(todo);
 		const int sh = __shfl(shard, leader);
-		const unsigned long long same = __ballot(want && shard == sh) & todo;
+		const unsigned long long same = ballot64(want && shard == sh) & todo;
 		unsigned base = 0;
 		if (lane == leader)
 			base = atomicAdd(next_count + vs * LINK_SHARDS + sh, (unsigned)__builtin_popcountll(same));
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 									const long span = hi - lo, stride = (span + 63) >> 6;
 									const long step = (long)(wl + 1) * stride;
 									const long probe = lo + (step < span ? step : span);
-									const int t = __builtin_popcountll(__ballot(CS[probe + 1] - s0 <= (unsigned long long)need));
+									const int t = __builtin_popcountll(ballot64(CS[probe + 1] - s0 <= (unsigned long long)need));
 									const long reach = (long)t * stride, next = (long)(t + 1) * stride;
 									hi = t == 64 ? hi : lo + (next < span ? next : span) - 1;
 									lo = lo + (reach < span ? reach : span);
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 		for (int r = 0; r < ROWS; ++r) {
 			const bool in = 64 * r < left;
 			const bool ns = in && mag[r] == 0;
-			const unsigned long long nm = __ballot(ns);
+			const unsigned long long nm = ballot64(ns);
 			const unsigned r1 = rank + (unsigned)popc_below(nm);
 			rank += (unsigned)__builtin_popcountll(nm);
 			const unsigned r2 = idx0 + 64u * r - r1;   // significant coefficients before this one
