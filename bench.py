@@ -246,12 +246,14 @@ def main():
 
     # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE doubled, WRITE_SIZE), collected
     # in a separate profiling run (profiles/): the counters cannot be read from inside this process
-    traffic = None
+    traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "r01_lift_traffic_pmc.json")
     if os.path.exists(tpath):
-        traffic = {"bytes_per_sample": round(json.load(open(tpath))["traffic_bytes_per_sample"], 2),
-                   "algorithmic_bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
-                   "source": "profiles/r01_lift_traffic_pmc.json (rocprofv3 --pmc, separate run of the same kernels)"}
+        per_sample = json.load(open(tpath))["traffic_bytes_per_sample"]
+        traffic = int(per_sample * samples)   # HBM bytes of one forward+inverse pass over the step's planes, like `achieved`
+        traffic_detail = {"bytes_per_sample": round(per_sample, 2), "algorithmic_bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
+                          "source": "profiles/r01_lift_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                    "over the same kernels, FETCH_SIZE doubled for gfx950; tools/pmc_lift.sh)"}
     if rank == 0:
         total_px = world * B * W * H * args.steps
         result = {
@@ -286,6 +288,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "algorithmic_bytes": LIFT_BYTES_PER_SAMPLE * samples,
                 "bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
                 "us_per_frame": round(lift_ms * 1e3 / B, 2),
             },
