@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="gray4096", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default per workload)")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU reference (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed on the CPU reference (0 = skip)")
     ap.add_argument("--lift-reps", type=int, default=20)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: all ranks share cuda:0")
