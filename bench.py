@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
-    "gray4096": (4096, 4096, 1, 32),
+    "gray4096": (4096, 4096, 1, 64),
     "rgb1080p": (1920, 1080, 3, 32),
     "rgb4096": (4096, 4096, 3, 4),
 }
