@@ -7,15 +7,20 @@ One "step" = one pass of the hot path over one batch of synthetic frames that
 are already resident in HBM: pixels -> (YCoCg) -> forward CDF 5/3 -> Hilbert
 linearisation -> bit-plane/RLE/VLI packer -> .dwt streams, then streams ->
 token walk -> plane scatter -> reconstruction -> inverse CDF 5/3 -> pixels.
-With N > 1 (one process per GPU, launched by torch.distributed.run) every rank
-runs the same per-GPU batch (weak scaling; frames are independent)
-and the encoded streams are gathered to rank 0 over RCCL inside the timed step.
+
+N > 1: one process per GPU.  Started without a launcher (`python bench.py --gpus N`)
+the parent — which never touches the GPU — starts the N ranks itself (dwt_amd/launch.py);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks
+come from the launcher.  Every rank runs the same per-GPU batch on its own frames (weak
+scaling; frames are independent); the encoded streams of every step are
+gathered to rank 0 over RCCL inside the timed region, one step behind the encoder.
 
 Prints ONE JSON line on rank 0.  The workload at N=1 is BASELINE.json configs[1]
 (4096x4096 8-bit gray, lossless).  `roofline` is measured live with HIP events
 around the forward+inverse lifting kernels on the same frames; `cpu_baseline`
 times the real reference binaries (oracle/_ref, built from /root/reference in
-the build container) on a bounded sample of the same frames.
+the build container) on a bounded sample of the same frames and the GPU's streams
+of those frames are compared with the reference's bytes.
 """
 import argparse
 import ctypes
@@ -33,26 +38,30 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
     "gray4096": (4096, 4096, 1, 64),
-    "rgb1080p": (1920, 1080, 3, 32),
-    "rgb4096": (4096, 4096, 3, 4),
+    "rgb1080p": (1920, 1080, 3, 64),
+    "rgb4096": (4096, 4096, 3, 16),
 }
 CONFIG_OF = {
     "gray4096": "BASELINE.json configs[1] geometry",
     "rgb1080p": "BASELINE.json configs[2] geometry",
     "rgb4096": "BASELINE.json configs[4] geometry",
 }
+GOLDEN_OF = {"gray4096": "g4096x4096", "rgb1080p": "c1920x1080", "rgb4096": "c4096x4096"}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LIFT_BYTES_PER_SAMPLE = 16      # int32 read + write, forward and inverse
+LIFT_READ_BYTES_PER_SAMPLE = 8  # the read-only variant
 
 
-def cpu_baseline(W, H, C, frames, first_frames_pix):
-    """Time the reference binaries (kind 'reference') or, without them, the oracle port, single thread."""
+def cpu_baseline(W, H, C, frames, first_frames_pix, gpu_streams=None):
+    """Time the reference binaries (kind 'reference') or, without them, the oracle port, single thread.
+    gpu_streams[i] (bytes) is compared with the .dwt the CPU path writes for frame i."""
     ref_enc = os.path.join(ROOT, "oracle", "_ref", "encode")
     ref_dec = os.path.join(ROOT, "oracle", "_ref", "decode")
     port = os.path.join(ROOT, "oracle", "orc_cli")
     kind = "reference" if os.path.exists(ref_enc) and os.path.exists(ref_dec) else "port"
     te = td = 0.0
     ok = True
+    same = 0
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(frames):
             src, dwt, dec = (os.path.join(tmp, n) for n in ("i.pnm", "o.dwt", "o.pnm"))
@@ -70,6 +79,8 @@ def cpu_baseline(W, H, C, frames, first_frames_pix):
             td += t2 - t1
             back = open(dec, "rb").read()
             ok = ok and back[back.index(b"\n") + 1:] == first_frames_pix[i].tobytes()
+            if gpu_streams is not None and open(dwt, "rb").read() == gpu_streams[i]:
+                same += 1
     return {
         "value": round(frames * W * H / (te + td) / 1e6, 4),
         "unit": "Mpixels/s",
@@ -78,7 +89,120 @@ def cpu_baseline(W, H, C, frames, first_frames_pix):
         "kind": kind,
         "sample": f"{frames} of the benchmark's {W}x{H}x{C} frames, encode+decode CLI round trip incl. PNM file I/O, "
                   f"1 thread ({te:.2f}s encode + {td:.2f}s decode), lossless={ok}",
-    }
+        "gpu_streams_equal_cpu_bytes": None if gpu_streams is None else f"{same}/{frames}",
+    }, (same == frames if gpu_streams is not None else None)
+
+
+class Runner:
+    """The hot path over one workload's resident batch, with the per-step stream gather when world > 1."""
+
+    def __init__(self, ctx, torch, dwt_amd, name, frames, rank, world, dev):
+        self.ctx, self.torch, self.dwt_amd, self.name = ctx, torch, dwt_amd, name
+        self.W, self.H, self.C, self.B = WORKLOADS[name]
+        if frames > 0:
+            self.B = frames
+        W, H, C, B = self.W, self.H, self.C, self.B
+        self.rank, self.world, self.dev = rank, world, dev
+        self.pix = ctx.synth_pixels(B, H, W, C, seed0=rank * B, kind=0)      # resident in HBM before the timed region
+        self.stride = ctx.lib.dwtx_encode_bound(W, H, C)
+        slots = 2 if world > 1 else 1
+        self.out = [torch.empty((B, self.stride), dtype=torch.uint8, device=dev) for _ in range(slots)]
+        self.info = [torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev) for _ in range(slots)]
+        self.dec = torch.empty((B, W * H * C), dtype=torch.uint8, device=dev)
+        self.gather = None
+        if world > 1:
+            from dwt_amd.dist import StreamGather
+            self.gather = StreamGather(B, dev, dst=0, slots=2)
+        self.k = 0
+
+    def step(self):
+        ctx, g, k = self.ctx, self.gather, self.k
+        s = k % len(self.out)
+        if g is not None:
+            g.wait(k - 2)                      # the gather that last read this slot's streams is done
+        streams, inf = ctx.encode_device(self.pix, out=self.out[s], info=self.info[s])
+        lens = ctx.stream_lengths(inf)
+        if g is not None:
+            # the one exchange step of the path: lengths now, the streams one step later (their lengths
+            # are on the host by then), to rank 0 over RCCL/xGMI, overlapping this rank's own work
+            g.post(k, streams, lens)
+            if k >= 1:
+                g.collect(k - 1)
+        d, dinfos = ctx.decode_device(streams, lens, self.W, self.H, self.C, out=self.dec)
+        self.k += 1
+        return streams, lens, d, dinfos
+
+    def drain(self):
+        """the last step's streams still have to reach rank 0 (inside the timed region)"""
+        if self.gather is not None and self.k >= 1:
+            self.gather.collect(self.k - 1)
+            self.gather.wait(self.k - 2)
+            self.gather.wait(self.k - 1)
+
+    def timed(self, steps, warmup, fence):
+        for _ in range(warmup):
+            self.step()
+        self.drain()
+        fence()
+        k0 = self.k
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = self.step()
+        self.drain()
+        fence()
+        return time.perf_counter() - t0, last, k0
+
+
+def coder_record(ctx, torch, dwt_amd, lin, W, H, C, B, stride, dev, reps=2):
+    """The entropy stage on its own (4 B coefficient + stream bytes per sample and direction)."""
+    cstreams = torch.empty((B, stride), dtype=torch.uint8, device=dev)
+    cinfo = torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev)
+    hinfo = (dwt_amd.DecodeInfo * B)()
+    samples = B * W * H * C
+
+    def enc():
+        rc = ctx.lib.dwtx_encode_planes(ctx.h, lin.data_ptr(), W, H, C, B, 0, cstreams.data_ptr(), stride, cinfo.data_ptr())
+        assert rc == 0, rc
+
+    enc()
+    clens = ctx.stream_lengths(cinfo)
+    lin_out = torch.empty_like(lin)
+
+    def dec():
+        rc = ctx.lib.dwtx_decode_planes(ctx.h, lin_out.data_ptr(), cstreams.data_ptr(), stride, clens.data_ptr(), W, H, C, B, -1,
+                                        ctypes.cast(hinfo, ctypes.c_void_p))
+        assert rc == 0, rc
+
+    dec()
+    torch.cuda.synchronize()
+    best = {"encode": 1e30, "decode": 1e30}
+    for _ in range(reps):
+        c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        c0.record()
+        enc()
+        c1.record()
+        dec()
+        c2.record()
+        torch.cuda.synchronize()
+        best["encode"] = min(best["encode"], c0.elapsed_time(c1))
+        best["decode"] = min(best["decode"], c1.elapsed_time(c2))
+    ok = bool(torch.equal(lin_out, lin))
+    nbytes = 4 * samples + int(clens.sum().item())
+    rec = {"what": "dwtx_encode_planes / dwtx_decode_planes alone on the same frames (linearised coefficients <-> streams)",
+           "algorithmic_bytes_per_step": nbytes, "coefficients_roundtrip": ok}
+    for name, ms in best.items():
+        rec[name] = {"ms_per_step": round(ms, 3), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return rec
+
+
+def golden_check(name, stream0):
+    gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
+    gname = GOLDEN_OF.get(name)
+    if not (gname and os.path.exists(gpath)):
+        return None
+    rec = json.load(open(gpath))[gname]
+    return len(stream0) == rec["dwt_len"] and hashlib.sha256(stream0).hexdigest() == rec["dwt_sha256"]
 
 
 def main():
@@ -90,21 +214,33 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default per workload)")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed on the CPU reference (0 = skip)")
     ap.add_argument("--lift-reps", type=int, default=20)
+    ap.add_argument("--extras", type=int, default=1, help="0: skip the workloads / single_frame sub-records")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--one-device", action="store_true", help="rehearsal: all ranks share cuda:0")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: all ranks share cuda:0 (use with --backend gloo)")
+    ap.add_argument("--dump-gathered", default="", help="rank 0 writes the last step's gathered streams here (tests)")
+    ap.add_argument("--geometry", type=int, nargs=3, metavar=("W", "H", "C"), default=None,
+                    help="tests: replace the workload's frame geometry (the line then names it; not a BASELINE config)")
     args = ap.parse_args()
+    if args.geometry:
+        W_, H_, C_ = args.geometry
+        WORKLOADS[args.workload] = (W_, H_, C_, WORKLOADS[args.workload][3])
+        CONFIG_OF[args.workload] = "test geometry, no BASELINE config"
+        GOLDEN_OF.pop(args.workload, None)
+        args.extras = 0
+
+    from dwt_amd import launch
+    if launch.needs_spawn(args.gpus):
+        # GPU-free parent: start one process per GPU and hand their status on
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = launch.check_world(args.gpus)
 
     import torch
     import torch.distributed as dist
 
     import dwt_amd
-    from dwt_amd.dist import gather_streams
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if args.one_device:
         local = 0
     torch.cuda.set_device(local)
@@ -117,63 +253,42 @@ def main():
     dev = torch.device("cuda", local)
     ctx = dwt_amd.Context(local)
 
-    W, H, C, B = WORKLOADS[args.workload]
-    if args.frames > 0:
-        B = args.frames
-    pix = ctx.synth_pixels(B, H, W, C, seed0=rank * B, kind=0)      # resident in HBM before the timed region
-    stride = ctx.lib.dwtx_encode_bound(W, H, C)
-    out = torch.empty((B, stride), dtype=torch.uint8, device=dev)
-    info = torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev)
-    dec = torch.empty((B, W * H * C), dtype=torch.uint8, device=dev)
-    gathered = {}
-
-    def step():
-        streams, inf = ctx.encode_device(pix, out=out, info=info)
-        lens = ctx.stream_lengths(inf)
-        work = None
-        if world > 1:
-            # the one exchange step of the path: lengths, then the streams, to rank 0 over RCCL/xGMI;
-            # the transfer overlaps this rank's own decode
-            gathered["streams"], gathered["lens"], work, gathered["send"] = gather_streams(streams, lens, dst=0,
-                                                                                           async_op=True)
-        d, dinfos = ctx.decode_device(streams, lens, W, H, C, out=dec)
-        if work is not None:
-            work.wait()
-        return streams, lens, d, dinfos
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        streams, lens, d, dinfos = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    run = Runner(ctx, torch, dwt_amd, args.workload, args.frames, rank, world, dev)
+    W, H, C, B = run.W, run.H, run.C, run.B
+    elapsed, (streams, lens, d, dinfos), k0 = run.timed(args.steps, args.warmup, fence)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- verification (outside the timed region) ---------------------------------
+    pix = run.pix
     lossless = bool(torch.equal(d.view(B, H, W, C), pix)) and all(i.status == 0 and not i.truncated for i in dinfos)
     lens_host = lens.cpu().tolist()
     golden_ok = None
+    gathered = None
     if rank == 0:
-        gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
-        gname = {"gray4096": "g4096x4096", "rgb1080p": "c1920x1080", "rgb4096": "c4096x4096"}.get(args.workload)
-        if gname and os.path.exists(gpath):
-            rec = json.load(open(gpath))[gname]
-            s0 = streams[0, : lens_host[0]].cpu().numpy().tobytes()
-            golden_ok = len(s0) == rec["dwt_len"] and hashlib.sha256(s0).hexdigest() == rec["dwt_sha256"]
+        golden_ok = golden_check(args.workload, streams[0, : lens_host[0]].cpu().numpy().tobytes())
     if world > 1:
         flag = torch.tensor([1 if lossless else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         lossless = bool(flag.item())
+        bufs, all_lens = run.gather.result(run.k - 1)
+        if rank == 0:
+            # rank 0's own rows of the gathered set must be the streams it encoded
+            mine_ok = all(bool(torch.equal(bufs[0][i, : lens_host[i]].to(dev), streams[i, : lens_host[i]])) for i in range(B))
+            gathered = {"world": world, "backend": args.backend, "frames": world * B, "own_rows_match": mine_ok,
+                        "bytes_last_step": int(all_lens.sum()),
+                        "bytes_all_steps_incl_warmup": run.gather.bytes_gathered, "bytes_per_rank_last_step": [int(all_lens[r * B:(r + 1) * B].sum()) for r in range(world)]}
+            if args.dump_gathered:
+                import numpy as np
+                np.savez(args.dump_gathered, lens=all_lens.numpy(),
+                         **{f"rank{r}": bufs[r].cpu().numpy() for r in range(world)})
 
     # ---- roofline of the lifting kernels, HIP events on the kernels' stream --------
     planes = ctx.planes_from_pixels(pix)
@@ -181,7 +296,7 @@ def main():
     back = torch.empty_like(planes)
     ctx.transformation_fwd(planes, pyr)
     ctx.transformation_inv(pyr, back)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     torch.cuda.synchronize()
     e0.record()
     for _ in range(args.lift_reps):
@@ -193,44 +308,21 @@ def main():
     lift_ok = bool(torch.equal(back, planes))
     samples = B * W * H * C
     achieved = LIFT_BYTES_PER_SAMPLE * samples / (lift_ms * 1e-3) / 1e9
+    # each direction on its own (same kernels, separate loops)
+    e0.record()
+    for _ in range(args.lift_reps):
+        ctx.transformation_fwd(planes, pyr)
+    e1.record()
+    for _ in range(args.lift_reps):
+        ctx.transformation_inv(pyr, back)
+    e2.record()
+    torch.cuda.synchronize()
+    fwd_ms, inv_ms = e0.elapsed_time(e1) / args.lift_reps, e1.elapsed_time(e2) / args.lift_reps
 
-    # ---- the entropy stage on its own (4 B coefficient + stream bytes per sample and direction) --
     lin = ctx.linearization(pyr)
-    del back
-    cstreams = torch.empty((B, stride), dtype=torch.uint8, device=dev)
-    cinfo = torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev)
-    hinfo = (dwt_amd.DecodeInfo * B)()
-
-    def coder_enc():
-        rc = ctx.lib.dwtx_encode_planes(ctx.h, lin.data_ptr(), W, H, C, B, 0, cstreams.data_ptr(), stride, cinfo.data_ptr())
-        assert rc == 0, rc
-
-    coder_enc()
-    clens = ctx.stream_lengths(cinfo)
-    lin_out = torch.empty_like(lin)
-
-    def coder_dec():
-        rc = ctx.lib.dwtx_decode_planes(ctx.h, lin_out.data_ptr(), cstreams.data_ptr(), stride, clens.data_ptr(), W, H, C, B, -1,
-                                        ctypes.cast(hinfo, ctypes.c_void_p))
-        assert rc == 0, rc
-
-    coder_dec()
-    torch.cuda.synchronize()
-    c0, c1, c2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    c0.record()
-    coder_enc()
-    c1.record()
-    coder_dec()
-    c2.record()
-    torch.cuda.synchronize()
-    coder_ok = bool(torch.equal(lin_out, lin))
-    coder_bytes = 4 * samples + int(clens.sum().item())
-    coder = {"what": "dwtx_encode_planes / dwtx_decode_planes alone on the same frames (linearised coefficients <-> streams)",
-             "algorithmic_bytes_per_step": coder_bytes, "coefficients_roundtrip": coder_ok}
-    for name, ms in (("encode", c0.elapsed_time(c1)), ("decode", c1.elapsed_time(c2))):
-        coder[name] = {"ms_per_step": round(ms, 3), "achieved_GBs": round(coder_bytes / (ms * 1e-3) / 1e9, 1),
-                       "frac_of_hbm_peak": round(coder_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    del lin, lin_out, cstreams
+    del back, planes
+    coder = coder_record(ctx, torch, dwt_amd, lin, W, H, C, B, run.stride, dev)
+    del lin, pyr
 
     # ---- stage breakdown (one extra untimed pass with events) ----------------------
     def timed(fn):
@@ -241,19 +333,27 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b), r
 
-    enc_ms, _ = timed(lambda: ctx.encode_device(pix, out=out, info=info))
-    dec_ms, _ = timed(lambda: ctx.decode_device(streams, lens, W, H, C, out=dec))
+    enc_ms, _ = timed(lambda: ctx.encode_device(pix, out=run.out[0], info=run.info[0]))
+    dec_ms, _ = timed(lambda: ctx.decode_device(run.out[0], ctx.stream_lengths(run.info[0]), W, H, C, out=run.dec))
 
-    # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE doubled, WRITE_SIZE), collected
-    # in a separate profiling run (profiles/): the counters cannot be read from inside this process
+    # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE in separate passes),
+    # collected in a separate profiling run (profiles/): the counters cannot be read from inside this process
     traffic = traffic_detail = None
-    tpath = os.path.join(ROOT, "profiles", "r01_lift_traffic_pmc.json")
-    if os.path.exists(tpath):
-        per_sample = json.load(open(tpath))["traffic_bytes_per_sample"]
-        traffic = int(per_sample * samples)   # HBM bytes of one forward+inverse pass over the step's planes, like `achieved`
-        traffic_detail = {"bytes_per_sample": round(per_sample, 2), "algorithmic_bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
-                          "source": "profiles/r01_lift_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
-                                    "over the same kernels, FETCH_SIZE doubled for gfx950; tools/pmc_lift.sh)"}
+    for tname in ("r02_lift_traffic_pmc.json", "r01_lift_traffic_pmc.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            per_sample = tj["traffic_bytes_per_sample"]
+            traffic = int(per_sample * samples)   # HBM bytes of one forward+inverse pass over the step's planes, like `achieved`
+            traffic_detail = {"bytes_per_sample": round(per_sample, 2), "algorithmic_bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
+                              "source": f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the "
+                                        "same kernels; tools/pmc_lift.sh)"}
+            for key in ("per_kernel", "planes"):
+                if key in tj:
+                    traffic_detail[key] = tj[key]
+            break
+
+    result = None
     if rank == 0:
         total_px = world * B * W * H * args.steps
         result = {
@@ -273,8 +373,10 @@ def main():
                 "workload": f"{W}x{H}x{C} 8-bit synthetic smooth+noise frames, lossless, {B} frames per GPU per step "
                             f"({CONFIG_OF[args.workload]})",
                 "frames_per_gpu": B,
-                "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of streams" if world > 1 else "1 GPU",
+                "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, streams gathered to rank 0 "
+                               f"({args.backend}) one step behind the encoder" if world > 1 else "1 GPU",
             },
+            "per_gpu_value": round(B * W * H * args.steps / elapsed / 1e6, 3),
             "bit_exact": {"roundtrip_lossless": lossless, "stream0_matches_reference_golden": golden_ok,
                           "lifting_roundtrip": lift_ok},
             "bytes_per_frame": int(sum(lens_host) / len(lens_host)),
@@ -287,18 +389,73 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "read_only_frac": round(LIFT_READ_BYTES_PER_SAMPLE * samples / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
                 "algorithmic_bytes": LIFT_BYTES_PER_SAMPLE * samples,
                 "bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
                 "us_per_frame": round(lift_ms * 1e3 / B, 2),
+                "forward_us_per_frame": round(fwd_ms * 1e3 / B, 2),
+                "inverse_us_per_frame": round(inv_ms * 1e3 / B, 2),
             },
         }
+        if gathered is not None:
+            result["gathered"] = gathered
+
+    if world == 1 and args.extras:
+        # BASELINE.json configs[1] literally (one frame), configs[2] and configs[4] geometry (short runs)
+        extras = {}
+        del run
+        torch.cuda.empty_cache()
+        one = Runner(ctx, torch, dwt_amd, "gray4096", 1, 0, 1, dev)
+        t1, (s1, l1, d1, i1), _ = one.timed(5, 2, fence)
+        em, _ = timed(lambda: ctx.encode_device(one.pix, out=one.out[0], info=one.info[0]))
+        dm, _ = timed(lambda: ctx.decode_device(one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, out=one.dec))
+        result["single_frame"] = {
+            "workload": "one 4096x4096x1 frame per step (BASELINE.json configs[1] literally)",
+            "value": round(5 * 4096 * 4096 / t1 / 1e6, 1), "unit": "Mpixels/s",
+            "encode_ms": round(em, 3), "decode_ms": round(dm, 3),
+            "lossless": bool(torch.equal(d1.view(1, 4096, 4096, 1), one.pix)),
+            "matches_reference_golden": golden_check("gray4096", s1[0, : int(l1[0])].cpu().numpy().tobytes()),
+        }
+        del one, s1, d1
+        for name in ("rgb1080p", "rgb4096"):
+            if name == args.workload:
+                continue
+            torch.cuda.empty_cache()
+            r2 = Runner(ctx, torch, dwt_amd, name, 0, 0, 1, dev)
+            t2, (s2, l2, d2, i2), _ = r2.timed(3, 1, fence)
+            ok2 = bool(torch.equal(d2.view(r2.B, r2.H, r2.W, r2.C), r2.pix)) and all(i.status == 0 and not i.truncated for i in i2)
+            g2 = golden_check(name, s2[0, : int(l2[0])].cpu().numpy().tobytes())
+            pl = ctx.planes_from_pixels(r2.pix)
+            lin2 = ctx.linearization(ctx.transformation_fwd(pl))
+            del pl
+            cr = coder_record(ctx, torch, dwt_amd, lin2, r2.W, r2.H, r2.C, r2.B, r2.stride, dev, reps=1)
+            del lin2
+            extras[name] = {
+                "workload": f"{r2.W}x{r2.H}x{r2.C}, {r2.B} frames per step, 3 steps ({CONFIG_OF[name]})",
+                "value": round(3 * r2.B * r2.W * r2.H / t2 / 1e6, 1), "unit": "Mpixels/s",
+                "Msamples_per_s": round(3 * r2.B * r2.W * r2.H * r2.C / t2 / 1e6, 1),
+                "ms_per_step": round(t2 / 3 * 1e3, 3), "bytes_per_frame": int(l2.sum().item() / r2.B),
+                "roundtrip_lossless": ok2, "stream0_matches_reference_golden": g2,
+                "coder_encode_frac_of_hbm_peak": cr["encode"]["frac_of_hbm_peak"],
+                "coder_decode_frac_of_hbm_peak": cr["decode"]["frac_of_hbm_peak"],
+                "coder_encode_ms": cr["encode"]["ms_per_step"], "coder_decode_ms": cr["decode"]["ms_per_step"],
+            }
+            del r2, s2, d2
+        result["workloads"] = extras
+
+    if rank == 0:
         if world == 1 and args.cpu_frames > 0:
-            sample = pix[: min(args.cpu_frames, B)].cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(W, H, C, sample.shape[0], sample)
+            nf = min(args.cpu_frames, B)
+            sample = pix[:nf].cpu().numpy()
+            gs = [streams[i, : lens_host[i]].cpu().numpy().tobytes() for i in range(nf)]
+            result["cpu_baseline"], same = cpu_baseline(W, H, C, nf, sample, gs)
+            result["bit_exact"]["streams_equal_reference_bytes"] = result["cpu_baseline"]["gpu_streams_equal_cpu_bytes"]
+            result["vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

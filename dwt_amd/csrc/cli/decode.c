@@ -24,12 +24,16 @@ int main(int argc, char **argv)
 	fclose(f);
 	if (!raw)
 		return 1;
-	if (len < 6) {   /* decode.c:145-155: get_byte() hits EOF inside the header */
-		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);       /* bytes.h:101 */
+	/* decode.c:145-155 reads the header byte by byte: a wrong magic byte ends the program silently,
+	 * only a MISSING byte prints get_byte()'s message (bytes.h:101) */
+	if (len >= 1 && raw[0] != 'W')
+		return 1;
+	if (len >= 2 && raw[1] != '5' && raw[1] != '6')
+		return 1;
+	if (len < 6) {
+		fprintf(stderr, "reached end of file \"%s\"\n", argv[1]);
 		return 1;
 	}
-	if (raw[0] != 'W' || (raw[1] != '5' && raw[1] != '6'))
-		return 1;
 	int W = (raw[2] | (raw[3] << 8)) + 1, H = (raw[4] | (raw[5] << 8)) + 1, C = raw[1] == '6' ? 3 : 1;
 	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)                           /* decode.c:158 */
 		return 1;

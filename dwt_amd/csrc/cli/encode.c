@@ -26,7 +26,10 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%s\n", dwtx_last_error());
 		return 1;
 	}
-	size_t stride = capacity > 0 ? ((size_t)capacity + 15) / 8 * 8 : dwtx_encode_bound(W, H, C);
+	/* a CAPACITY beyond what the image can need must not size the buffers */
+	size_t stride = dwtx_encode_bound(W, H, C);
+	if (capacity > 0 && ((size_t)capacity + 15) / 8 * 8 < stride)
+		stride = ((size_t)capacity + 15) / 8 * 8;
 	uint8_t *out = (uint8_t *)malloc(stride);
 	size_t len = 0;
 	dwtx_stats st;

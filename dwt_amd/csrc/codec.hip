@@ -10,8 +10,11 @@ enum { SLOT_CD_A = 16, SLOT_CD_B, SLOT_CD_INFO, SLOT_CD_IO, SLOT_CD_IO2, SLOT_CD
 
 extern "C" size_t dwtx_encode_bound(int W, int H, int C)
 {
-	// generous: noise costs ~9 bit/sample, allow 2 bytes per sample
-	size_t b = (size_t)2 * W * H * C + 4096;
+	// 8-bit sources: at most 11 bit planes per coefficient (9 bits of pixel range, +1 for YCoCg chroma, +1
+	// for the HH gain of the 5/3 lifting), each plane costs a coefficient at most 2 bits (a raw refinement
+	// bit, or a pass-1 symbol: VLI(0) at order 0 is one bit, plus the sign) -> below 3 bytes per sample;
+	// uniform noise measures ~9 bit/sample
+	size_t b = (size_t)3 * W * H * C + 4096;
 	return (b + 7) / 8 * 8;
 }
 
@@ -19,9 +22,9 @@ extern "C" size_t dwtx_encode_bound(int W, int H, int C)
 extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int C, int n, long capacity,
 	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info)
 {
-	if (!ctx || !dev_pix || !dev_out || !dev_info || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || W > 65536 || H > 65536 ||
-		(C != 1 && C != 3) || n < 1)
+	if (!ctx || !dev_pix || !dev_out || !dev_info || (C != 1 && C != 3) || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	const size_t bytes = sizeof(int) * (size_t)W * H * C * n;
 	int *a = (int *)dwtx_scratch(ctx, SLOT_CD_A, bytes);
 	int *b = (int *)dwtx_scratch(ctx, SLOT_CD_B, bytes);
@@ -50,6 +53,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 {
 	if (!ctx || !dev_streams || !dev_lens || !dev_pix || !host_info || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	dwtx_geom g;
 	int rc = dwtx_geometry(&g, W, H);
 	if (rc)
@@ -153,8 +157,9 @@ static int sync_all(dwtx_ctx *ctx)
 extern "C" int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *pix, int W, int H, int C, int n, long capacity,
 	uint8_t *out, size_t out_stride, size_t *out_lens, dwtx_stats *stats)
 {
-	if (!ctx || !pix || !out || !out_lens || (out_stride & 7) || n < 1 || W < 1 || H < 1 || (C != 1 && C != 3))
+	if (!ctx || !pix || !out || !out_lens || (out_stride & 7) || n < 1 || (C != 1 && C != 3))
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	const int P = part_size(W, H, C, n), parts = (n + P - 1) / P;
 	const size_t img_bytes = (size_t)W * H * C;
 	int rc = dwtx_need_copy_stream(ctx);
@@ -262,10 +267,14 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 	// decode.c:142-159: geometry comes from the first stream's header; all streams of a batch share it
 	if (lens[0] < 6 || streams[0] != 'W' || (streams[1] != '5' && streams[1] != '6'))
 		return DWTX_ERR_ARG;
+	for (int i = 0; i < n; ++i)
+		if (lens[i] > stream_stride) {
+			dwtx_set_error("stream %d: %zu bytes do not fit the stream stride %zu", i, lens[i], stream_stride);
+			return DWTX_ERR_ARG;
+		}
 	const int C = streams[1] == '6' ? 3 : 1;
 	const int W = (streams[2] | (streams[3] << 8)) + 1, H = (streams[4] | (streams[5] << 8)) + 1;
-	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)
-		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	dwtx_geom g;
 	dwtx_geometry(&g, W, H);
 	int levels_max = -1;

@@ -45,6 +45,20 @@ void *dwtx_scratch(dwtx_ctx *ctx, int slot, size_t bytes);
 
 static inline int dwtx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Image sizes the kernels' int indices support: the reference itself indexes with int
+// (encode.c:40 `channels*(width*y+x)`), here one plane (W*H) must stay below 2^31.
+static inline bool dwtx_dims_ok(int W, int H)
+{
+	return W >= DWTX_MIN_LEN && H >= DWTX_MIN_LEN && W <= 65536 && H <= 65536 && (long)W * H <= 0x7fffffffL - 4096;
+}
+#define DWTX_CHECK_DIMS(W, H)                                                              \
+	do {                                                                                    \
+		if (!dwtx_dims_ok(W, H)) {                                                          \
+			dwtx_set_error("unsupported image size %dx%d (8..65536 per side, W*H < 2^31)", W, H); \
+			return DWTX_ERR_ARG;                                                            \
+		}                                                                                   \
+	} while (0)
+
 // scratch slot assignment
 enum {
 	SLOT_LIFT_A = 0,

@@ -1455,9 +1455,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int H, int C, int n, long capacity,
 	uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
 {
-	if (!ctx || !lin || !out || !dev_info || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || W > 65536 || H > 65536 ||
-		(C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
+	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	PackGeom g;
 	{
 		int lengths[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS];

@@ -817,7 +817,8 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	for (int i = 0; i < 48; ++i)
 		I.missing[i] = 0;
 	const unsigned char *s8 = streams + img * stream_stride;
-	const unsigned long long len = lens[img];
+	// a length beyond the stride cannot be real data: only the bytes inside the stride are read
+	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
 	// decode.c:142-159 header
 	if (len < 6 || s8[0] != 'W' || s8[1] != (g.C == 3 ? '6' : '5') ||
 		(s8[2] | (s8[3] << 8)) + 1 != g.W || (s8[4] | (s8[5] << 8)) + 1 != g.H)
@@ -1356,9 +1357,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
 	int (*done)(void *user, int first, int count), void *user)
 {
-	if (!ctx || !lin || !streams || !dev_lens || !host_info || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || W > 65536 ||
-		H > 65536 || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 || (stream_stride & 7) || stream_stride < 64)
+	if (!ctx || !lin || !streams || !dev_lens || !host_info || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 ||
+		(stream_stride & 7) || stream_stride < 64)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	UnpackGeom g;
 	{
 		int lengths[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS];
@@ -1383,7 +1385,9 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	DWork w;
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
+#ifdef DWTX_DEBUG_HOOKS   // tools/dbg_walker.py: device address for the walker's cycle counters (never in the shipped build)
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
+#endif
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
 	w.BW = (long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 64;   // 2 bits per symbol
 	{

@@ -204,6 +204,12 @@ def _odd_dwts():
         "other_width": good[:2] + bytes([99, 0]) + good[4:],
         "empty": b"",
         "one_byte": b"W",
+        "one_foreign_byte": b"X",
+        "two_bytes_bad_number": b"W7",
+        "two_bytes": b"W5",
+        "three_bytes": b"W5\x01",
+        "five_bytes": b"W6\x24\x00\x34",
+        "short_foreign": b"P6\n3",
         "header_only": good[:6],
         "zeros_after_header": good[:6] + bytes(400),
         "ones_after_header": good[:6] + b"\xff" * 400,

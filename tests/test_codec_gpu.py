@@ -296,3 +296,45 @@ def test_statistics_when_capacity_cuts_into_header_or_root(ctx):
             want, ost = orc.encode(pix, cap)
             assert data == want, (W, H, Cn, cap)
             assert (st.meta_bits, st.root_bits, st.total_bits, st.kib) == (ost.meta_bits, ost.root_bits, ost.total_bits, ost.kib), (W, H, Cn, cap)
+
+
+def test_length_beyond_the_stream_stride_is_refused_or_clamped(ctx):
+    """A byte length that does not fit the stride cannot be real data: the host-buffer entry point refuses it,
+    the device entry point reads only what the stride holds (no access beyond the buffer)."""
+    import ctypes as C
+
+    import torch
+
+    import dwt_amd
+
+    pix = orc.synth(200, 120, 1, 9, 0)
+    data, _ = ctx.encode(pix)
+    stride = (len(data) + 64 + 7) // 8 * 8
+    host = np.zeros((1, stride), dtype=np.uint8)
+    host[0, : len(data)] = np.frombuffer(data, dtype=np.uint8)
+    lens = (C.c_size_t * 1)(stride + 4096)
+    out = np.empty((1, 200 * 120), dtype=np.uint8)
+    ow, oh, oc = (C.c_int * 1)(), (C.c_int * 1)(), (C.c_int * 1)()
+    rc = ctx.lib.dwtx_decode_images(ctx.h, host.ctypes.data, stride, C.cast(lens, C.c_void_p), 1, -1, out.ctypes.data, 200 * 120, ow, oh, oc)
+    assert rc == -3
+    dev = torch.from_numpy(host).to(ctx.device)
+    dl = torch.tensor([1 << 40], dtype=torch.int64, device=ctx.device)
+    got, infos = ctx.decode_device(dev, dl, 200, 120, 1)
+    # the zero padding after the real stream decodes as more (empty) data: same picture as the oracle on the padded bytes
+    want = orc.decode(host[0].tobytes())
+    lo = infos[0].level + 1
+    g = orc.geometry(200, 120)
+    assert (g.widths[lo], g.heights[lo]) == want.shape[1::-1]
+    assert (got[0, : want.size].cpu().numpy() == want.reshape(-1)).all()
+
+
+def test_image_sizes_beyond_int_indexing_are_refused(ctx):
+    """W*H >= 2^31 would overflow the int geometry (the reference's own int indexing, encode.c:40): a clean
+    argument error instead of a device fault."""
+    import torch
+
+    tiny = torch.zeros(64, dtype=torch.uint8, device=ctx.device)
+    info = torch.zeros(256, dtype=torch.uint8, device=ctx.device)
+    for W, H in ((50000, 50000), (65536, 32768), (65537, 8), (8, 7)):
+        rc = ctx.lib.dwtx_encode_device(ctx.h, tiny.data_ptr(), W, H, 1, 1, 0, tiny.data_ptr(), 64, info.data_ptr())
+        assert rc == -3, (W, H, rc)
