@@ -11,30 +11,38 @@
 //   k_hist    one wave per 1024-coefficient tile: cumulative magnitude
 //             histogram cum[p] = #(|v| < 2^p) by ballot/popcount.  Every
 //             (tile, plane) symbol count — zeros, ones, refinement bits — is a
-//             difference of two entries, so the coefficients are read once here
-//             for all planes; max plane count per channel by atomicMax.
+//             difference of two entries; max plane count per channel by atomicMax.
 //   k_plan    per image (serial, tiny): header + root image + plane counts
 //             written straight into the stream, the segment schedule, VLI order
 //             after the header.
-//   k_entries_* an "entry" is (segment, tile).  Symbol counts per
-//             entry from the histograms, exclusive scans -> first token slot
-//             and refinement rank of every entry.
-//   k_tokens  one wave per tile, all planes: classify 64 coefficients per row at
-//             each plane that codes the tile; every newly significant one
-//             becomes a token (zero run since the previous one in this tile,
-//             sign).
+//   k_entries_* an "entry" is (segment, tile).  Symbol counts per entry from the
+//             histograms, exclusive scans -> first token slot and refinement rank
+//             of every entry, per segment its refinement block in the staging buffer.
+//   k_code    one wave per tile, every lane owns 16 CONSECUTIVE coefficients, all
+//             planes in one pass over the coefficients (read once): per-lane counts
+//             of "magnitude below 2^q" packed into nibble fields, one cross-lane DPP
+//             scan of the packed counts, then each non-zero coefficient knows the
+//             plane it turns significant in, the zeros before it and its rank among
+//             that plane's ones from two table look-ups -> 16-bit tokens (zero run
+//             since the previous one of the tile, sign) written in stream order;
+//             refinement bits compressed per lane and plane and written to a
+//             staging bit buffer at their final rank (encode.c:84-93).
 //   k_carry_* batch-wide segmented scan of pending zero runs across entries,
 //             segment ends (phantom terminators, rle.h:79-89) and the final
 //             flush; patches the first token of each entry.
-//   k_orders_fast  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0) per 64-token
-//             group from the chains started at order 0 and 31 (they almost
-//             always meet); k_lut/k_chain*/k_orders redo flagged images exactly
-//             as a scan over monotone maps on 32 states.
+//   k_gorder  the VLI order recurrence o' = max(ilog2(v+2^o)-2,0): one lane per
+//             64-token group walks the chains started at order 0 and 31 (they
+//             almost always meet: the group's exit order is then known whatever
+//             it was entered with) and, with its entry order, the group's bit
+//             count; k_lut/k_chain*/k_gorder_exact redo flagged images exactly as
+//             a scan over monotone maps on 32 states.
 //   k_bitscan per image: exclusive scan of chunk bit totals -> bit offsets.
 //   k_clear_stream  zeroes the words the stream will occupy.
-//   k_emit    one lane per four tokens: their codes glued into one bit string,
-//             a wave's strings merged in LDS, words merged with atomicOr.
-//   k_refine  one wave per tile, all planes: refinement bits, compacted through LDS.
+//   k_emit    one lane per 64-token group, entry order and bit position known:
+//             walks its tokens once more and writes their codes (bits.h:58-78)
+//             through an LDS window of the wave's stretch of the stream.
+//   k_refcopy refinement blocks from the staging buffer to their place behind
+//             each segment's tokens (a shifted copy).
 #include "dwtx_internal.h"
 
 #include <stdlib.h>
@@ -51,7 +59,11 @@ constexpr int SUB = 64;               // tokens per lane
 constexpr int CHUNK = SUB * 64;       // tokens per wave
 constexpr int GROUP = 64;             // chunks per group
 
-constexpr unsigned F_SIGN = 1, F_HAS_SIGN = 2, F_BREAK = 4, F_FLUSH = 8, F_VOID = 16;
+// A token is 16 bits: zero run (0xfff: the run is in tok_big[t]), sign of the one that ends it, and what
+// kind of slot it is.  Ones carry a sign; a segment's break slot (phantom terminator, rle.h:79-89) and the
+// final flush (encode.c:221) do not; a void slot emits nothing (but a break still has its refinement block).
+constexpr unsigned T_RUN = 0x0fffu, T_ESC = 0x0fffu, T_SIGN = 1u << 12, T_BREAK = 1u << 13, T_VOID = 1u << 14,
+	T_NOSIGN = 1u << 15;
 
 struct PackGeom {
 	int levels, C, W, H;
@@ -91,7 +103,8 @@ struct Work {
 	int *seg_desc;              // [n][MAX_SEGS]   c | l<<4 | (p+1)<<8
 	int *seg_ebase;             // [n][MAX_SEGS+1]
 	unsigned *seg_refs;         // [n][MAX_SEGS]
-	unsigned long long *seg_rawoff; // [n][MAX_SEGS] bit offset of the segment's refinement block
+	unsigned long long *seg_rawoff; // [n][MAX_SEGS] bit offset of the segment's refinement block in the stream
+	unsigned long long *seg_stage;  // [n][MAX_SEGS+1] word offset of the segment's refinement block in the staging buffer
 	unsigned *brk_tok;          // [n][MAX_SEGS] token index of the segment's break slot
 	int *segidx;                // [n][3][16][MAX_PLANES] -> k+1 of the segment coding (channel, level, plane)
 	// per entry
@@ -99,11 +112,13 @@ struct Work {
 	unsigned *ent_tokbase;      // [n][ES+1]
 	unsigned *ent_refscum;      // [n][ES+1]
 	// per token
-	unsigned *tok_run;          // [n][TS]
-	unsigned char *tok_flag;    // [n][TS]
-	unsigned char *tok_ord;     // [n][TS] VLI order each token is coded with
-	unsigned short *tok_off;    // [n][TS] bit offset inside its group of 64 tokens
-	// per chunk
+	unsigned short *tok16;      // [n][TS]
+	unsigned *tok_big;          // [n][TS] only touched where tok16 says T_ESC
+	// refinement bits of every segment, in coefficient order, each segment's block starting on a word
+	unsigned *stage;            // [n][SW]
+	// per 64-token group / per chunk of groups
+	unsigned char *grp_ord;     // [n][NCS*64] VLI order the group is entered with
+	unsigned long long *lane_bits;     // [n][NCS*64] bit offset of the group inside its chunk
 	unsigned char *sublut;      // [n][NCS*64][32]
 	unsigned char *lut;         // [n][NCS][32]
 	unsigned char *glut;        // [n][NGS][32]
@@ -111,13 +126,12 @@ struct Work {
 	unsigned char *group_entry; // [n][NGS]
 	unsigned long long *chunk_bits;    // [n][NCS]
 	unsigned long long *chunk_base;    // [n][NCS]
-	unsigned long long *lane_bits;     // [n][NCS*64] per 64-token group: bit offset inside its wave's chunk
 	RunMap *carry_agg;                 // [n][NCB] map of each block of 1024 entries
 	unsigned *carry_in;                // [n][NCB] pending run entering the block
 	unsigned *ent_blk;                 // [n][NCB][2] token slots / refinement bits of each block of 1024 entries, then their scan
 	unsigned long long *stream_bits;   // [n] bits of the whole stream before any capacity clip (k_bitscan -> k_clear_stream)
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
-	long ES, TS, NCS, NGS, NCB;
+	long ES, TS, NCS, NGS, NCB, SW;
 	int NT;
 };
 
@@ -133,6 +147,28 @@ __device__ __forceinline__ int popc_below(unsigned long long m)
 
 __device__ __forceinline__ int ilog2u(unsigned v) { return 31 - __builtin_clz(v); }
 
+// Lanes of ONE wave hand data to each other through LDS: the wave's DS operations execute in order, so all
+// that is needed is that the compiler keeps the accesses on their side of this point.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inclusive prefix sum over the 64 lanes in six DPP adds: row_shr 1,2,4,8 inside the rows of 16, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ unsigned wave_incl_add(unsigned v)
+{
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+	return v;
+}
+
 // vli.h:67-84 in closed form: order o, value v -> o* 
 __device__ __forceinline__ int vli_top(int o, unsigned v) { return ilog2u(v + (1u << o)); }
 __device__ __forceinline__ int vli_next(int top) { return top >= 2 ? top - 2 : 0; }
@@ -145,6 +181,14 @@ __device__ __forceinline__ void seg_unpack(int d, int &c, int &l, int &p)
 }
 
 // ------------------------------------------------------------------ k_hist ---
+// Lane L owns coefficients 16L .. 16L+15 of the tile (four 16-byte loads).  With t = number of magnitude
+// bits, adding 0x1111.. << 4t to a 64-bit register counts "t <= q" for all q = 0..15 at once in its
+// nibbles (two registers of eight coefficients each: a nibble holds up to 8); the lane totals, widened
+// to 16-bit fields, are summed over the wave with DPP adds.
+
+struct __attribute__((packed, aligned(4))) Int4U {
+	int x, y, z, w;
+};
 
 __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
 {
@@ -156,38 +200,64 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
-	const long ring0 = g.pixels[l], ring1 = g.pixels[l + 1];
-	const long base = ring0 + (long)(tile - g.tile_first[l]) * TILE;
-	const int *src = lin + plane * g.total;
-	unsigned m[ROWS];
-	unsigned mx = 0;
-	int valid = 0;
+	const long ring1 = g.pixels[l + 1];
+	const long base = g.pixels[l] + (long)(tile - g.tile_first[l]) * TILE;
+	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const int *src = lin + (long)plane * g.total + base;
+	const int first = 16 * lane;
+	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
+	int val[16];
+	if (nvalid == TILE) {
 #pragma unroll
-	for (int r = 0; r < ROWS; ++r) {
-		const long i = base + r * 64 + lane;
-		const bool in = i < ring1;
-		const int v = in ? src[i] : 0;
-		m[r] = in ? (unsigned)(v < 0 ? -v : v) : 0xffffffffu;   // out-of-ring lanes count nowhere
-		mx |= in ? m[r] : 0u;
-		valid += __builtin_popcountll(ballot64(in));
+		for (int q = 0; q < 4; ++q) {
+			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + first + 4 * q);
+			val[4 * q] = v4.x;
+			val[4 * q + 1] = v4.y;
+			val[4 * q + 2] = v4.z;
+			val[4 * q + 3] = v4.w;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			val[i] = i < nv ? src[first + i] : 0;
+	}
+	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
+	unsigned long long Ra = 0, Rb = 0;
+	unsigned mx = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const int v = val[i];
+		const unsigned a = (unsigned)(v < 0 ? -v : v);
+		mx |= a;
+		int t = a ? 32 - __builtin_clz(a) : 0;
+		t = i < nv ? t : 16;   // past the ring's end: counted nowhere
+		const unsigned long long m = t < 16 ? ONES << (4 * t) : 0ull;
+		if (i < 8)
+			Ra += m;
+		else
+			Rb += m;
+	}
+	const unsigned long long ev = (Ra & M0F) + (Rb & M0F);                 // byte b: #(t <= 2b) of this lane
+	const unsigned long long od = ((Ra >> 4) & M0F) + ((Rb >> 4) & M0F);   // byte b: #(t <= 2b+1)
+	unsigned D[8];   // D[b] = #(t <= 2b) | #(t <= 2b+1) << 16 over the whole tile (lane 63 after the scan)
+#pragma unroll
+	for (int b = 0; b < 8; ++b) {
+		const unsigned x = ((unsigned)(ev >> (8 * b)) & 0xffu) | ((unsigned)(od >> (8 * b)) & 0xffu) << 16;
+		D[b] = wave_incl_add(x);
 	}
 	for (int o = 32; o; o >>= 1)
 		mx |= __shfl_xor(mx, o);
-	// bits needed by the largest magnitude of the tile: cum[p] = valid for every p >= that
-	const int top = mx ? ilog2u(mx) + 1 : 0;
-	int mine = valid;
-	for (int p = 0; p < top; ++p) {
-		int c = 0;
-#pragma unroll
-		for (int r = 0; r < ROWS; ++r)
-			c += __builtin_popcountll(ballot64(m[r] < (1u << p)));
-		mine = lane == p ? c : mine;
+	unsigned short *cum = w.cum + ((long)plane * w.NT + tile) * NCUM;
+	if (lane == 63) {
+		*reinterpret_cast<uint4 *>(cum) = make_uint4(D[0], D[1], D[2], D[3]);
+		*reinterpret_cast<uint4 *>(cum + 8) = make_uint4(D[4], D[5], D[6], D[7]);
+	} else if (lane >= 16 && lane < NCUM) {
+		cum[lane] = (unsigned short)nvalid;   // |v| < 2^16 for every stream this coder accepts (k_plan checks the plane count)
 	}
-	if (lane < NCUM)
-		w.cum[((long)plane * w.NT + tile) * NCUM + lane] = (unsigned short)mine;
 	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
 	// 100k waves hammering one word per plane would serialise in L2: the value only grows, so a
 	// (possibly stale) plain read filters out all but the first few
+	const int top = mx ? ilog2u(mx) + 1 : 0;
 	if (lane == 0 && top > __hip_atomic_load(w.planes_dev + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 		atomicMax(w.planes_dev + plane, top);
 }
@@ -490,28 +560,299 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_finish(Work w)
 
 __global__ __launch_bounds__(ENT_BLOCK) void k_entries_segs(Work w)
 {
+	__shared__ unsigned wsum[16];
 	const int img = blockIdx.x;
 	const int K = w.info[img].K;
 	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
 	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1), *refscum = w.ent_refscum + img * (w.ES + 1);
-	for (int k = threadIdx.x; k < K; k += ENT_BLOCK) {
-		w.seg_refs[(long)img * MAX_SEGS + k] = refscum[eb[k + 1]] - refscum[eb[k]];
+	static_assert(MAX_SEGS <= ENT_BLOCK, "one thread per segment");
+	const int k = threadIdx.x;
+	unsigned words = 0;
+	if (k < K) {
+		const unsigned refs = refscum[eb[k + 1]] - refscum[eb[k]];
+		w.seg_refs[(long)img * MAX_SEGS + k] = refs;
 		const int last = eb[k + 1] - 1;
 		w.brk_tok[(long)img * MAX_SEGS + k] = tokbase[last] + w.ent_ones[img * w.ES + last];
+		words = (refs + 31u) >> 5;
+	}
+	// every segment's refinement block starts on a word of the staging buffer (at most 2^31 bits each)
+	unsigned total;
+	const unsigned at = block_excl_scan(words, wsum, total);
+	if (k <= K && k <= MAX_SEGS)
+		w.seg_stage[(long)img * (MAX_SEGS + 1) + k] = at;
+}
+
+// k_code writes the first and the last staging word of an entry's refinement bits with atomicOr (they are
+// shared with the neighbouring entries) and the words between with plain stores: only the shared ones must
+// start as zeros.
+__global__ __launch_bounds__(ENT_BLOCK) void k_stage_zero(Work w)
+{
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
+	if (e >= I.E)
+		return;
+	const unsigned refs = w.ent_refs[img * w.ES + e];
+	if (!refs)
+		return;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const int k = seg_of_entry(eb, I.K, e);
+	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+	const unsigned long long bit0 = (w.seg_stage[(long)img * (MAX_SEGS + 1) + k] << 5) + (refscum[e] - refscum[eb[k]]);
+	unsigned *st = w.stage + img * w.SW;
+	st[bit0 >> 5] = 0u;
+	st[(bit0 + refs - 1) >> 5] = 0u;
+}
+
+// ------------------------------------------------------------------ k_code ---
+// One wave per 1024-coefficient tile; lane L owns coefficients 16L .. 16L+15 of the tile, so everything
+// that is sequential in the reference's scan order (encode.c:60-95) is sequential inside a lane and a
+// prefix over lanes.  Let t = number of magnitude bits of a coefficient (0 for zero).  At plane p a
+// coefficient is a zero symbol if t <= p, the one of that plane if t == p+1, a refinement bit if t >= p+2.
+// With Z[q] = #(coefficients before me with t <= q):
+//   zeros before me at my plane p = t-1:      Z[t-1]
+//   my rank among the ones of plane p:        Z[t] - Z[t-1]
+//   refinement bits before me at plane p:     (#coefficients before me) - Z[p+1]
+// Z = (prefix over the lanes before me) + (count inside my lane).  The lane part is kept for all q at once
+// as 16 nibbles of one 64-bit register (adding 0x1111.. << 4t per coefficient); the prefix over lanes is one
+// DPP scan of the same counts widened to 16-bit fields.  Tokens of plane p take the tile's slots
+// [#(t >= p+2), #(t >= p+1)): plane-major, in coefficient order — the order of the stream.
+
+constexpr int TABP = 18;             // dwords per lane in the class table (9 pairs: ds_read_b64 conflict-free over 32 lanes)
+constexpr int ROWW = 34;             // words per staging row of one plane (31 + 1024 bits + slack)
+
+struct CodeLds {
+	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1] | (t-1) << 12,  first slot of plane t-1 + Z[t] - Z[t-1] };
+	                                 // more: [lane][t-1] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
+	unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 10 | plane << 12
+	unsigned rows[(MAX_PLANES - 1) * ROWW];
+	unsigned short cum[MAX_PLANES + 2];   // the tile's histogram: #(t <= q), q = 0..16
+	unsigned gb[MAX_PLANES];         // plane p: token index of the entry's first token minus the plane's first slot; ~0: plane not coded
+	unsigned long long rb[MAX_PLANES];    // plane p: bit position of the entry's refinement bits in the staging buffer
+	int ent[MAX_PLANES];             // plane p: entry index, -1 = the plane is not coded for this tile
+};
+
+// NQ = number of count fields q = 0 .. NQ-1 (one nibble each): 8 when the channel has at most 8 bit planes (the
+// counts then live in 32-bit registers), else 16.  Z[NQ] needs no field: it counts every coefficient.
+template <int NQ>
+struct Nib;
+template <>
+struct Nib<8> {
+	typedef unsigned T;
+	static constexpr T ONES = 0x11111111u, M0F = 0x0f0f0f0fu;
+};
+template <>
+struct Nib<16> {
+	typedef unsigned long long T;
+	static constexpr T ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
+};
+
+template <int NQ, bool FULL>
+__device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], const Work &w, int img, int lane, int nvalid, int nv, int vb,
+	int P, unsigned my_tokbase, int my_ent, unsigned long long my_rb)
+{
+	typedef typename Nib<NQ>::T R_t;
+	constexpr R_t ONES = Nib<NQ>::ONES, M0F = Nib<NQ>::M0F;
+	constexpr int NB = NQ / 4;   // dwords of 16-bit fields per parity
+
+	// ---- pass A: magnitudes, signs, per-lane counts of (t <= q) as nibbles (two halves: a nibble holds up to 8) ----
+	unsigned mag[16];
+	int tt[16];
+	unsigned sgn = 0;
+	R_t Ra = 0, Rb = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const int v = val[i];
+		const unsigned a = (unsigned)(v < 0 ? -v : v);
+		mag[i] = a;   // 0 for the coefficients past the ring's end
+		sgn |= ((unsigned)v >> 31) << i;
+		int t = 32 - __clz((int)a);
+		t = t < NQ ? t : NQ;
+		tt[i] = t;
+		const int te = FULL || i < nv ? t : NQ;   // past the end: counted nowhere
+		const R_t m = te < NQ ? ONES << (4 * te) : (R_t)0;
+		if (i < 8)
+			Ra += m;
+		else
+			Rb += m;
+	}
+	// bytes: ev byte b = #(t <= 2b), od byte b = #(t <= 2b+1) inside this lane (up to 16)
+	const R_t ev = (Ra & M0F) + (Rb & M0F);
+	const R_t od = ((Ra >> 4) & M0F) + ((Rb >> 4) & M0F);
+	// 16-bit fields for the scan over lanes: E[b] = #(t <= 4b) | #(t <= 4b+2) << 16, O[b] = #(t <= 4b+1) | #(t <= 4b+3) << 16
+	unsigned E[NB], O[NB], cE[NB], cO[NB];
+	const int nq = (P >> 2) + 1 < NB ? (P >> 2) + 1 : NB;   // groups of four q that matter (q <= P); uniform
+#pragma unroll
+	for (int b = 0; b < NB; ++b) {
+		const unsigned xe = (unsigned)(ev >> (16 * b)) & 0xffffu, xo = (unsigned)(od >> (16 * b)) & 0xffffu;
+		const unsigned e0 = (xe & 0xffu) | ((xe & 0xff00u) << 8), o0 = (xo & 0xffu) | ((xo & 0xff00u) << 8);
+		unsigned ei = 0, oi = 0;
+		if (b < nq) {
+			ei = wave_incl_add(e0);
+			oi = wave_incl_add(o0);
+		}
+		cE[b] = (unsigned)__builtin_amdgcn_readlane((int)ei, 63);   // the tile's totals
+		cO[b] = (unsigned)__builtin_amdgcn_readlane((int)oi, 63);
+		E[b] = ei - e0;   // exclusive: the lanes before this one
+		O[b] = oi - o0;
+	}
+	// Z over the lanes before me / the whole tile, q a compile-time constant after unrolling
+#define ZL(q) ((((q) & 1 ? O[((q) >> 2) % NB] : E[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
+#define CT(q) ((((q) & 1 ? cO[((q) >> 2) % NB] : cE[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
+#pragma unroll
+	for (int t = 1; t <= NQ; ++t) {
+		if (t <= P) {
+			const unsigned zlo = ZL(t - 1);
+			const unsigned zhi = t < NQ ? ZL(t) : (unsigned)vb;
+			const unsigned ct = t < NQ ? CT(t) : (unsigned)nvalid;
+			if (NQ == 8)
+				*reinterpret_cast<uint2 *>(&L.tab[lane * TABP + 2 * (t - 1)]) =
+					make_uint2(zlo | (unsigned)(t - 1) << 12, (unsigned)nvalid - ct + zhi - zlo);
+			else
+				L.tab[lane * TABP + t - 1] = zlo | (zhi - zlo) << 10 | ((unsigned)nvalid - ct) << 20;
+		}
+	}
+	if (lane == 0) {
+#pragma unroll
+		for (int q = 0; q <= MAX_PLANES; ++q)
+			L.cum[q] = (unsigned short)(q < P && q < NQ ? CT(q) : (unsigned)nvalid);
+	}
+#undef ZL
+#undef CT
+	wave_sync();
+
+	// ---- pass B: every non-zero coefficient drops its zero count into its token slot (zeros into a dummy slot) ----
+	{
+		R_t R = 0;
+		constexpr int NB8 = NQ == 8 ? 8 : 2;   // look-ups in flight (registers: the 16-plane variant keeps 64-bit counts)
+#pragma unroll
+		for (int h = 0; h < 16 / NB8; ++h) {
+			uint2 ent[NB8];
+#pragma unroll
+			for (int i = NB8 * h; i < NB8 * h + NB8; ++i) {   // a batch of table look-ups first: their latencies overlap
+				const int tm = tt[i] > 0 ? tt[i] - 1 : 0;
+				if (NQ == 8) {
+					ent[i % NB8] = *reinterpret_cast<const uint2 *>(&L.tab[lane * TABP + 2 * tm]);
+				} else {
+					const unsigned e = L.tab[lane * TABP + tm];
+					ent[i % NB8] = make_uint2((e & 0x3ffu) | (unsigned)tm << 12, (e >> 20) + ((e >> 10) & 0x3ffu));
+				}
+			}
+#pragma unroll
+			for (int i = NB8 * h; i < NB8 * h + NB8; ++i) {
+				const int t = tt[i];
+				const int tm = t > 0 ? t - 1 : 0;
+				const unsigned x = (unsigned)(R >> (4 * tm));
+				const unsigned lz_lo = x & 15u;
+				const unsigned lz_hi = t < NQ ? (x >> 4) & 15u : (unsigned)i;
+				const unsigned slot = mag[i] ? ent[i % NB8].y + lz_hi - lz_lo : (unsigned)(TILE + (lane & 7));
+				L.zs[slot] = (unsigned short)(ent[i % NB8].x + lz_lo + ((sgn >> i) & 1u) * 0x400u);
+				const int te = FULL || i < nv ? t : NQ;
+				R += te < NQ ? ONES << (4 * te) : (R_t)0;
+			}
+		}
+	}
+	// token base of every plane relative to its first slot (lane p holds plane p's)
+	if (lane < MAX_PLANES) {
+		L.gb[lane] = my_ent >= 0 ? my_tokbase - ((unsigned)nvalid - L.cum[lane + 1]) : ~0u;
+		L.ent[lane] = my_ent;
+		L.rb[lane] = my_rb;
+	}
+	wave_sync();
+
+	// ---- tokens out, slot-parallel (two slots per lane): run = zeros since the previous one of the same plane in this tile ----
+	{
+		unsigned short *tok16 = w.tok16 + img * w.TS;
+		const int nt = nvalid - (int)L.cum[0];   // non-zero coefficients = tokens of the tile
+		const unsigned *zs2 = reinterpret_cast<const unsigned *>(L.zs);
+		unsigned carry = 0;                      // slot 128r-1 (in the high half)
+		for (int r = 0; r * 128 < nt; ++r) {
+			const int s0 = r * 128 + 2 * lane;
+			const unsigned a2 = s0 < nt ? zs2[s0 >> 1] : 0u;
+			const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp((int)carry, (int)a2, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps carry
+			carry = (unsigned)__builtin_amdgcn_readlane((int)a2, 63);
+			const unsigned a0 = a2 & 0xffffu, a1 = a2 >> 16, bp = b2 >> 16;
+			// a plane's tokens are consecutive slots: the first one of a plane is where the plane changes
+			if (s0 < nt) {
+				const unsigned z = a0 & 0x3ffu, p = a0 >> 12;
+				const unsigned run = s0 == 0 || (bp >> 12) != p ? z : z - (bp & 0x3ffu);
+				const unsigned gb = L.gb[p];
+				if (gb != ~0u)
+					tok16[gb + (unsigned)s0] = (unsigned short)(run | ((a0 >> 10) & 1u) << 12);
+			}
+			if (s0 + 1 < nt) {
+				const unsigned z = a1 & 0x3ffu, p = a1 >> 12;
+				const unsigned run = (a0 >> 12) != p ? z : z - (a0 & 0x3ffu);
+				const unsigned gb = L.gb[p];
+				if (gb != ~0u)
+					tok16[gb + (unsigned)s0 + 1u] = (unsigned short)(run | ((a1 >> 10) & 1u) << 12);
+			}
+		}
+		// zeros after the tile's last one of each plane: what the tile hands to the run counter (k_carry_*)
+		if (lane < MAX_PLANES && L.ent[lane] >= 0) {
+			const int p = lane;
+			const unsigned c0 = L.cum[p], c1 = L.cum[p + 1];
+			const unsigned ones = c1 - c0, slot0 = (unsigned)nvalid - c1;
+			const unsigned tz = ones ? c0 - (L.zs[slot0 + ones - 1] & 0x3ffu) : c0;
+			w.ent_tz[img * w.ES + L.ent[p]] = (unsigned short)tz;
+		}
+	}
+
+	// ---- pass C: refinement bits (encode.c:84-93), per plane a <= 16-bit string per lane at rank (coefficients before) - Z[p+1] ----
+	for (int p = P - 2; p >= 0; --p) {
+		const int refs = nvalid - (int)L.cum[p + 1];
+		if (refs <= 0 || L.ent[p] < 0)
+			continue;   // uniform
+		const unsigned thr = 2u << p;
+		unsigned acc = 0, cnt = 0;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const bool isref = mag[i] >= thr;
+			acc |= (isref ? (mag[i] >> p) & 1u : 0u) << cnt;
+			cnt += isref ? 1u : 0u;
+		}
+		const unsigned zl = L.tab[lane * TABP + (NQ == 8 ? 2 : 1) * (p + 1)] & 0x3ffu;   // Z[p+1] of the lanes before
+		const unsigned pos = (unsigned)(L.rb[p] & 31ull) + ((unsigned)vb - zl);
+		if (cnt) {
+			unsigned *row = L.rows + p * ROWW;
+			const unsigned sh = pos & 31u;
+			atomicOr(&row[pos >> 5], acc << sh);
+			if (sh + cnt > 32u)
+				atomicOr(&row[(pos >> 5) + 1], acc >> (32u - sh));
+		}
+	}
+	wave_sync();
+	{
+		unsigned *stage = w.stage + img * w.SW;
+		for (int p = P - 2; p >= 0; --p) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				continue;
+			const unsigned long long bit0 = L.rb[p];
+			const int nw = (int)(((unsigned)(bit0 & 31ull) + (unsigned)refs + 31u) >> 5);
+			if (lane < nw) {
+				const unsigned v = L.rows[p * ROWW + lane];
+				unsigned *dst = stage + (bit0 >> 5) + lane;
+				if (lane == 0 || lane == nw - 1) {
+					if (v)
+						atomicOr(dst, v);
+				} else {
+					*dst = v;
+				}
+			}
+		}
 	}
 }
 
-// ---------------------------------------------------------------- k_tokens ---
-// One wave per 1024-coefficient tile, all planes: the tile is read once into
-// registers, then every plane that codes it classifies the same 16 rows.
-
-__global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restrict__ lin, Work w)
+__global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
 {
-	const int lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	__shared__ CodeLds lds[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int tile = blockIdx.x * 4 + wv;
 	const int plane = blockIdx.y;
 	if (tile >= w.NT)
-		return;
+		return;   // whole wave; nothing below synchronises across waves
+	CodeLds &L = lds[wv];
 	const int img = plane / g.C, c = plane - img * g.C;
 	const ImgInfo &I = w.info[img];
 	int l = 0;
@@ -520,64 +861,55 @@ __global__ __launch_bounds__(256) void k_tokens(PackGeom g, const int *__restric
 	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
-	const int *src = lin + (long)plane * g.total;
-	unsigned m[ROWS];       // magnitude, bit 31 = negative
-	bool in[ROWS];
+	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const int P = I.planes[c] < MAX_PLANES ? I.planes[c] : MAX_PLANES;
+	const int *src = lin + (long)plane * g.total + base;
+	const int first = 16 * lane;
+	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;   // this lane's coefficients
+	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
+
+	// ---- the coefficients, once ----
+	int val[16];
+	if (nvalid == TILE) {
 #pragma unroll
-	for (int r = 0; r < ROWS; ++r) {
-		const long i = base + r * 64 + lane;
-		in[r] = i < ring1;
-		const int v = in[r] ? src[i] : 0;
-		m[r] = (unsigned)(v < 0 ? -v : v) | (v < 0 ? 0x80000000u : 0u);
+		for (int q = 0; q < 4; ++q) {
+			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + first + 4 * q);
+			val[4 * q] = v4.x;
+			val[4 * q + 1] = v4.y;
+			val[4 * q + 2] = v4.z;
+			val[4 * q + 3] = v4.w;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			val[i] = i < nv ? src[first + i] : 0;
 	}
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int *sx = w.segidx + ((long)img * 48 + c * 16 + l) * MAX_PLANES;
-	unsigned *tok_run = w.tok_run + img * w.TS;
-	unsigned char *tok_flag = w.tok_flag + img * w.TS;
-	const int pstart = I.planes[c] > 0 ? I.planes[c] - 1 : 0;
-	// zeros before each one of the current row, by rank of the one: the run of a one is the difference
-	// to its predecessor's count (LDS hand-over instead of per-lane 64-bit mask arithmetic)
-	__shared__ unsigned zbefore[4][64];
-	unsigned *zb = zbefore[threadIdx.x >> 6];
-	for (int p = pstart; p >= 0; --p) {
-		const int k1 = sx[p];
-		if (!k1)
-			continue;
-		const int e = eb[k1 - 1] + j;
-		if (!w.ent_ones[img * w.ES + e]) {   // no token from this tile at this plane: its zeros just pass through
-			if (lane == 0)
-				w.ent_tz[img * w.ES + e] = w.ent_zeros[img * w.ES + e];
-			continue;
+	// per-plane bookkeeping of this tile's entries (lanes 0..15 take a plane each): three dependent look-ups
+	// whose results are only needed after the first passes over the coefficients — they stay in registers till then
+	unsigned my_tokbase = 0;
+	int my_ent = -1;
+	unsigned long long my_rb = 0;
+	if (lane < MAX_PLANES) {
+		const int p = lane;
+		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
+		if (k1) {
+			const int k = k1 - 1;
+			const int e0 = w.seg_ebase[(long)img * (MAX_SEGS + 1) + k];
+			my_ent = e0 + j;
+			const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
+			my_rb = (w.seg_stage[(long)img * (MAX_SEGS + 1) + k] << 5) + (refscum[my_ent] - refscum[e0]);
+			my_tokbase = w.ent_tokbase[img * (w.ES + 1) + my_ent];
 		}
-		unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
-		unsigned pending = 0;   // zeros since the last one of this tile (uniform)
-#pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			const unsigned mag = m[r] & 0x7fffffffu;
-			const bool refine = (mag >> (p + 1)) != 0;
-			const bool one = in[r] && !refine && ((mag >> p) & 1u);
-			const bool zero = in[r] && !refine && !one;
-			const unsigned long long om = ballot64(one), zm = ballot64(zero);
-			if (om) {
-				const unsigned z = (unsigned)popc_below(zm), k = (unsigned)popc_below(om);
-				if (one)
-					zb[k] = z;
-				__builtin_amdgcn_wave_barrier();
-				if (one) {
-					const unsigned run = k ? z - zb[k - 1] : pending + z;
-					tok_run[tb + k] = run;
-					tok_flag[tb + k] = (unsigned char)(F_HAS_SIGN | ((m[r] >> 31) ? F_SIGN : 0));
-				}
-				__builtin_amdgcn_wave_barrier();
-				const int last = 63 - __builtin_clzll(om);
-				pending = last == 63 ? 0u : (unsigned)__builtin_popcountll(zm >> (last + 1));
-				tb += (unsigned)__builtin_popcountll(om);
-			} else {
-				pending += (unsigned)__builtin_popcountll(zm);
-			}
-		}
-		if (lane == 0)
-			w.ent_tz[img * w.ES + e] = (unsigned short)pending;
+	}
+	for (int i = lane; i < (MAX_PLANES - 1) * ROWW; i += 64)
+		L.rows[i] = 0u;
+	if (P <= 8) {
+		if (nvalid == TILE)
+			code_tile<8, true>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+		else
+			code_tile<8, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+	} else {
+		code_tile<16, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
 	}
 }
 
@@ -593,6 +925,15 @@ __device__ __forceinline__ RunMap compose(RunMap a, RunMap b)   // a then b
 	r.keep = a.keep & b.keep;
 	r.add = b.keep ? a.add + b.add : b.add;
 	return r;
+}
+
+__device__ __forceinline__ void token_store(const Work &w, int img, unsigned t, unsigned run, unsigned flags)
+{
+	if (run >= T_ESC) {
+		w.tok_big[img * w.TS + t] = run;
+		run = T_ESC;
+	}
+	w.tok16[img * w.TS + t] = (unsigned short)(run | flags);
 }
 
 // The scan runs over all entries of a batch at once: k_carry_local reduces blocks of 1024
@@ -689,10 +1030,8 @@ __global__ __launch_bounds__(CARRY_BLOCK) void k_carry_blocks(Work w)
 		s = total.add + (total.keep ? s : 0u);
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) {
-		w.tok_run[img * w.TS + I.T - 1] = s;                 // encode.c:221 rle_flush: always emitted
-		w.tok_flag[img * w.TS + I.T - 1] = (unsigned char)F_FLUSH;
-	}
+	if (threadIdx.x == 0)
+		token_store(w, img, I.T - 1, s, T_NOSIGN);   // encode.c:221 rle_flush: always emitted
 }
 
 __global__ __launch_bounds__(CARRY_BLOCK) void k_carry_apply(Work w)
@@ -721,29 +1060,279 @@ __global__ __launch_bounds__(CARRY_BLOCK) void k_carry_apply(Work w)
 		return;
 	const unsigned s_blk = w.carry_in[img * w.NCB + blockIdx.x];
 	const unsigned s_in = ex.add + (ex.keep ? s_blk : 0u);
-	unsigned *tok_run = w.tok_run + img * w.TS;
 	const unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
-	if (has_one)
-		tok_run[tb] += s_in;
+	if (has_one && s_in) {   // the entry's first token: its run began before this tile
+		const unsigned tk = w.tok16[img * w.TS + tb];
+		token_store(w, img, tb, (tk & T_RUN) + s_in, tk & ~T_RUN);
+	}
 	if (seg_end) {   // the break slot
 		const unsigned s = own.add + (own.keep ? s_in : 0u);
-		const unsigned idx = tb + w.ent_ones[img * w.ES + e];
-		tok_run[idx] = s;
-		w.tok_flag[img * w.TS + idx] = (unsigned char)(F_BREAK | ((refs && s) ? 0u : F_VOID));
+		token_store(w, img, tb + w.ent_ones[img * w.ES + e], s, T_BREAK | T_NOSIGN | ((refs && s) ? 0u : T_VOID));
 	}
 }
 
-// ------------------------------------------------------------------- k_lut ---
-// Lanes 0..31 of each half-wave are the 32 possible VLI orders at the start of
-// a 4096-token chunk; the half-wave walks the chunk once and every lane follows
-// its own start state.  Snapshots at every 64-token boundary (sublut) let the
-// next pass start each lane's 64 tokens from the right order.
+// ---------------------------------------------------------- token walks ---
+// The order pass and the emitter both give every lane 64 CONSECUTIVE tokens (a "group") of a wave's
+// window of 4096.  The window is read as coalesced 16-byte pieces and laid out in LDS as one row per
+// group (pitch 34 dwords: lane j's ds_read_b64 of its q-th token quad hits bank pair 34j + 2q, all
+// different over 32 lanes).  Tokens outside the image's [0, T) become void.
+
+constexpr int WROW = 34;
+constexpr unsigned VOID2 = (T_VOID | T_NOSIGN) * 0x00010001u;
+
+__device__ __forceinline__ void stage_tokens(unsigned *rows, const unsigned short *tok16, long t0, long T, int lane)
+{
+#pragma unroll
+	for (int it = 0; it < 8; ++it) {
+		const int off = it * 512 + lane * 8;
+		const long t = t0 + off;
+		uint4 v = make_uint4(VOID2, VOID2, VOID2, VOID2);
+		if (t >= 0 && t + 8 <= T) {
+			v = *reinterpret_cast<const uint4 *>(tok16 + t);
+		} else if (t + 8 > 0 && t < T) {
+			unsigned h[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e)
+				h[e] = t + e >= 0 && t + e < T ? (unsigned)tok16[t + e] : (T_VOID | T_NOSIGN);
+			v = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+		}
+		unsigned *dst = rows + (off >> 6) * WROW + ((off & 63) >> 1);
+		*reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+		*reinterpret_cast<uint2 *>(dst + 2) = make_uint2(v.z, v.w);
+	}
+}
+
+// a token pair holds an escape (run field 0xfff) / a break slot
+__device__ __forceinline__ bool pair_has_esc(unsigned x) { return (((x & 0x0fff0fffu) + 0x00010001u) & 0x10001000u) != 0u; }
+__device__ __forceinline__ bool pair_has_break(unsigned x) { return (x & (T_BREAK * 0x00010001u)) != 0u; }
 
 __device__ __forceinline__ int vli_step(int o, unsigned v, bool skip)
 {
 	const int nx = vli_next(vli_top(o, v));
 	return skip ? o : nx;
 }
+
+__device__ __forceinline__ unsigned token_run(unsigned tk, const unsigned *big, long t)
+{
+	const unsigned r = tk & T_RUN;
+	return r == T_ESC ? big[t] : r;
+}
+
+__device__ __forceinline__ long find_break_seg(const unsigned *btok, int K, unsigned t)
+{
+	int lo = 0, hi = K - 1;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (btok[mid] < t)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long long v, unsigned long long &total)
+{
+	const int lane = lane_id();
+	unsigned long long inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned long long t = __shfl_up(inc, o);
+		if (lane >= o)
+			inc += t;
+	}
+	total = __shfl(inc, 63);
+	return inc - v;
+}
+
+// the order chain of one group's 64 tokens from order o (tokens of this lane's row; tb = index of its first token)
+__device__ __forceinline__ int walk_order(const unsigned *my, const unsigned *big, long tb, int o)
+{
+#pragma unroll 4
+	for (int q = 0; q < 16; ++q) {
+		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+		const unsigned xs[2] = { x2.x, x2.y };
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const unsigned x = xs[h];
+			unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
+			if (pair_has_esc(x)) {
+				v0 = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
+				v1 = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			}
+			o = vli_step(o, v0, x & T_VOID);
+			o = vli_step(o, v1, (x >> 16) & T_VOID);
+		}
+	}
+	return o;
+}
+
+// two chains at once (start orders 0 and 31): see k_gorder.  Once the chains of every lane have met
+// (typically after 10-20 tokens) the rest of the group is walked with one chain.
+__device__ __forceinline__ void walk_order2(const unsigned *my, const unsigned *big, long tb, int &lo, int &hi)
+{
+	int q = 0;
+	bool met = false;   // uniform
+	for (; q < 16; q += 2) {
+		if (q && !ballot64(lo != hi)) {
+			met = true;
+			break;
+		}
+#pragma unroll
+		for (int qq = 0; qq < 2; ++qq) {
+			const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * (q + qq));
+			const unsigned xs[2] = { x2.x, x2.y };
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const unsigned x = xs[h];
+				unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
+				if (pair_has_esc(x)) {
+					v0 = token_run(x & 0xffffu, big, tb + 4 * (q + qq) + 2 * h);
+					v1 = token_run(x >> 16, big, tb + 4 * (q + qq) + 2 * h + 1);
+				}
+				lo = vli_step(lo, v0, x & T_VOID);
+				hi = vli_step(hi, v0, x & T_VOID);
+				lo = vli_step(lo, v1, (x >> 16) & T_VOID);
+				hi = vli_step(hi, v1, (x >> 16) & T_VOID);
+			}
+		}
+	}
+	for (; q < 16; ++q) {
+		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+		const unsigned xs[2] = { x2.x, x2.y };
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const unsigned x = xs[h];
+			unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
+			if (pair_has_esc(x)) {
+				v0 = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
+				v1 = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			}
+			lo = vli_step(lo, v0, x & T_VOID);
+			lo = vli_step(lo, v1, (x >> 16) & T_VOID);
+		}
+	}
+	if (met)
+		hi = lo;   // hi was left behind in the single-chain part
+}
+
+// bits of one group's tokens coded from order o, and of the refinement blocks that follow its break slots
+__device__ __forceinline__ void walk_bits(const unsigned *my, const unsigned *big, long tb, int o, bool count_raw,
+	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
+{
+	tokbits = 0;
+	rawbits = 0;
+#pragma unroll 4
+	for (int q = 0; q < 16; ++q) {
+		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+		const unsigned xs[2] = { x2.x, x2.y };
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const unsigned x = xs[h];
+			unsigned v[2] = { x & T_RUN, (x >> 16) & T_RUN };
+			if (pair_has_esc(x)) {
+				v[0] = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
+				v[1] = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			}
+#pragma unroll
+			for (int e = 0; e < 2; ++e) {
+				const unsigned tk = e ? x >> 16 : x & 0xffffu;
+				const int top = vli_top(o, v[e]);
+				const unsigned nb = (unsigned)(2 * top - o + 1) + ((tk & T_NOSIGN) ? 0u : 1u);
+				tokbits += (tk & T_VOID) ? 0u : nb;
+				o = (tk & T_VOID) ? o : vli_next(top);
+			}
+			if (pair_has_break(x) && count_raw) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e)
+					if ((e ? x >> 16 : x) & T_BREAK)
+						rawbits += srefs[find_break_seg(btok, K, (unsigned)(tb + 4 * q + 2 * h + e))];
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------- k_gorder ---
+// The order map of a token is monotone, so every start state ends between the chains started at 0
+// and at 31; over 64 tokens those two almost always meet (orders decay by 2 per small value), and then
+// the group's exit order is a constant, whatever it was entered with.  One lane per 64-token group:
+// walk the 0- and the 31-chain; if they met, the NEXT group's entry order is known, and a second walk
+// counts the group's bits.  Lane 0 only serves as the predecessor of lane 1 (63 groups of output per
+// wave).  A group whose chains did not meet is resolved exactly as soon as its own entry order is
+// known; only if that chain of knowledge breaks is the image flagged and the exact hierarchical pass
+// (k_lut ... k_gorder_exact) redoes it.
+constexpr int FSUBS = 63;
+
+struct WalkLds {
+	unsigned tok[64 * WROW];
+};
+
+__global__ __launch_bounds__(256) void k_gorder(Work w)
+{
+	__shared__ WalkLds lds[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const long wave = (long)blockIdx.x * 4 + wv;
+	const int img = blockIdx.y;
+	const ImgInfo &I = w.info[img];
+	const long T = I.T;
+	const long nsub = (T + SUB - 1) / SUB;
+	if (wave * FSUBS >= nsub)
+		return;
+	const unsigned short *tok16 = w.tok16 + img * w.TS;
+	const unsigned *big = w.tok_big + img * w.TS;
+	unsigned *rows = lds[wv].tok;
+	const long S = wave * FSUBS - 1 + lane;          // this lane's group (lane 0: predecessor only)
+	const long tfirst = (wave * FSUBS - 1) * SUB;    // first token of the wave's window (-64 for wave 0)
+	stage_tokens(rows, tok16, tfirst, T, lane);
+	wave_sync();
+	const unsigned *my = rows + lane * WROW;
+	const long tb = S * SUB;
+	int lo = 0, hi = 31;
+	walk_order2(my, big, tb, lo, hi);
+	const bool valid = S >= 0 && S < nsub;
+	int exitv = lo;
+	bool exit_known = lo == hi || !valid;
+	int o = 0;
+	bool entry_known = false;
+	for (int it = 0; it < 4; ++it) {
+		o = __shfl_up(exitv, 1);
+		entry_known = __shfl_up((int)exit_known, 1) != 0 && lane >= 1;
+		if (S == 0) {
+			o = I.order0;
+			entry_known = true;
+		}
+		const bool resolve = valid && !exit_known && entry_known;
+		if (!ballot64(resolve))
+			break;
+		const int e = walk_order(my, big, tb, o);
+		if (resolve) {
+			exitv = e;
+			exit_known = true;
+		}
+	}
+	if (ballot64(lane >= 1 && valid && !entry_known)) {
+		if (lane == 0)
+			atomicOr(w.slow + img, 1);
+		return;   // the exact pass takes the whole image
+	}
+	const bool produces = lane >= 1 && valid;
+	unsigned tokbits;
+	unsigned long long rawbits;
+	walk_bits(my, big, tb, o, produces, w.brk_tok + (long)img * MAX_SEGS, w.seg_refs + (long)img * MAX_SEGS, I.K, tokbits, rawbits);
+	unsigned long long total;
+	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
+	if (produces) {
+		w.lane_bits[img * w.NCS * 64 + S] = pre;
+		w.grp_ord[img * w.NCS * 64 + S] = (unsigned char)o;
+	}
+	if (lane == 0)
+		w.chunk_bits[img * w.NCS + wave] = total;
+}
+
+// ------------------------------------------------------------------- k_lut ---
+// Exact pass (flagged images only).  Lanes 0..31 of each half-wave are the 32 possible VLI orders at
+// the start of a 4096-token chunk; the half-wave walks the chunk once and every lane follows its own
+// start state.  Snapshots at every 64-token boundary (sublut) give every group its entry order once
+// the chunk's own entry is known.
 
 __device__ __forceinline__ void lut_body(const Work &w, long vbx, int img)
 {
@@ -755,16 +1344,21 @@ __device__ __forceinline__ void lut_body(const Work &w, long vbx, int img)
 	if (chunk_a >= nchunks)
 		return;
 	const bool live = chunk < nchunks;
-	const unsigned *run = w.tok_run + img * w.TS;
-	const unsigned char *flag = w.tok_flag + img * w.TS;
+	const unsigned short *tok16 = w.tok16 + img * w.TS;
+	const unsigned *big = w.tok_big + img * w.TS;
 	unsigned char *sub = w.sublut + (img * w.NCS + chunk) * 64 * 32;
 	// lane i holds token i of a 64-token row for both chunks; bit 31 = "void" (runs are < 2^31).
 	// Tokens are broadcast with v_readlane (no LDS traffic), each half picks its own chunk's.
-	// The next row is loaded while the current one is walked.
+	auto one = [&](long t) -> unsigned {
+		if (t >= (long)T)
+			return 0x80000000u;
+		const unsigned tk = tok16[t];
+		return token_run(tk, big, t) | ((tk & T_VOID) ? 0x80000000u : 0u);
+	};
 	auto fetch = [&](int q, unsigned &ra, unsigned &rb) {
-		const long ta = chunk_a * CHUNK + q * SUB + lane, tb = ta + CHUNK;
-		ra = ta < (long)T ? run[ta] | ((flag[ta] & F_VOID) ? 0x80000000u : 0u) : 0x80000000u;
-		rb = tb < (long)T ? run[tb] | ((flag[tb] & F_VOID) ? 0x80000000u : 0u) : 0x80000000u;
+		const long ta = chunk_a * CHUNK + q * SUB + lane;
+		ra = one(ta);
+		rb = one(ta + CHUNK);
 	};
 	int o = s;
 	unsigned na, nb;
@@ -855,432 +1449,209 @@ __global__ __launch_bounds__(1024) void k_chain_image(Work w)
 	}
 }
 
-// ---------------------------------------------------------------- k_orders ---
-// One lane per 64 tokens, now with the true start order: record each token's
-// order and the bits it will occupy; wave-scan the lane totals.
-
-__device__ __forceinline__ long find_break_seg(const unsigned *btok, int K, unsigned t)
+// One lane per 64-token group, now with the true start order (chunk entry state -> sublut): the group's bits.
+__device__ __forceinline__ void gorder_exact_body(const Work &w, unsigned *rows, long chunk, int img)
 {
-	int lo = 0, hi = K - 1;
-	while (lo < hi) {
-		const int mid = (lo + hi) >> 1;
-		if (btok[mid] < t)
-			lo = mid + 1;
-		else
-			hi = mid;
-	}
-	return lo;
-}
-
-__device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long long v, unsigned long long &total)
-{
-	const int lane = lane_id();
-	unsigned long long inc = v;
-	for (int o = 1; o < 64; o <<= 1) {
-		const unsigned long long t = __shfl_up(inc, o);
-		if (lane >= o)
-			inc += t;
-	}
-	total = __shfl(inc, 63);
-	return inc - v;
-}
-
-// The token arrays are read as coalesced 64-token rows and transposed through LDS
-// (row pitch 65 words: lane j then reads [j][t] conflict-free), because lane j
-// needs the 64 CONSECUTIVE tokens j*64 .. j*64+63 of the wave's 4096-token chunk.
-// Per token it records the VLI order it is coded with and its bit offset inside
-// the lane's 64 tokens (refinement blocks not counted); k_emit then writes the
-// tokens in parallel.
-constexpr int ORD_WAVES = 2;
-
-struct OrdTile {
-	unsigned run[64][65];
-	unsigned char flag[64][68];
-	unsigned char ord[64][68];
-	unsigned short off[64][66];
-};
-
-__device__ __forceinline__ void orders_body(const Work &w, OrdTile *tiles, long vbx, int img)
-{
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const long chunk = vbx * ORD_WAVES + wv;
+	const int lane = threadIdx.x & 63;
 	const ImgInfo &I = w.info[img];
-	const unsigned T = I.T;
-	const long nchunks = ((long)T + CHUNK - 1) / CHUNK;
+	const long T = I.T;
+	const long nchunks = (T + CHUNK - 1) / CHUNK;
 	if (chunk >= nchunks)
 		return;
-	const unsigned *run = w.tok_run + img * w.TS;
-	const unsigned char *flag = w.tok_flag + img * w.TS;
-	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
-	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	OrdTile &tile = tiles[wv];
-	const long tbase = chunk * CHUNK;
-#pragma unroll 8
-	for (int r = 0; r < 64; ++r) {
-		const long t = tbase + r * 64 + lane;
-		const bool in = t < (long)T;
-		tile.run[r][lane] = in ? run[t] : 0u;
-		tile.flag[r][lane] = in ? flag[t] : (unsigned char)F_VOID;
-	}
-	__builtin_amdgcn_wave_barrier();   // each wave only reads back its own tile
-
-	// this lane's 64 tokens start at the order recorded for (chunk entry state, sub-chunk)
-	int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
-	const long t0 = tbase + (long)lane * SUB;
-	unsigned tokbits = 0;              // bits of this lane's tokens so far
-	unsigned long long rawbits = 0;    // refinement blocks that follow break tokens of this lane
-	for (int t = 0; t < SUB; ++t) {
-		const unsigned f = tile.flag[lane][t];
-		tile.ord[lane][t] = (unsigned char)o;
-		tile.off[lane][t] = (unsigned short)tokbits;
-		if (!(f & F_VOID)) {
-			const int top = vli_top(o, tile.run[lane][t]);
-			tokbits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
-			o = vli_next(top);
-		}
-		if (f & F_BREAK)
-			rawbits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + t))];
-	}
+	const unsigned short *tok16 = w.tok16 + img * w.TS;
+	const unsigned *big = w.tok_big + img * w.TS;
+	wave_sync();   // the previous virtual block's reads of the rows are done
+	stage_tokens(rows, tok16, chunk * CHUNK, T, lane);
+	wave_sync();
+	const long S = chunk * 64 + lane;
+	const int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
+	const bool produces = S * SUB < T;
+	unsigned tokbits;
+	unsigned long long rawbits;
+	walk_bits(rows + lane * WROW, big, S * SUB, o, produces, w.brk_tok + (long)img * MAX_SEGS, w.seg_refs + (long)img * MAX_SEGS, I.K,
+		tokbits, rawbits);
 	unsigned long long total;
-	const unsigned long long pre = wave_excl_scan64(tokbits + rawbits, total);
-	w.lane_bits[(img * w.NCS + chunk) * 64 + lane] = pre;
+	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
+	if (produces) {
+		w.lane_bits[img * w.NCS * 64 + S] = pre;
+		w.grp_ord[img * w.NCS * 64 + S] = (unsigned char)o;
+	}
 	if (lane == 0)
 		w.chunk_bits[img * w.NCS + chunk] = total;
-	__builtin_amdgcn_wave_barrier();
-	unsigned char *ord = w.tok_ord + img * w.TS;
-	unsigned short *off = w.tok_off + img * w.TS;
-#pragma unroll 8
-	for (int r = 0; r < 64; ++r) {
-		const long t = tbase + r * 64 + lane;
-		if (t < (long)T) {
-			ord[t] = tile.ord[r][lane];
-			off[t] = tile.off[r][lane];
-		}
-	}
-	__builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64 * ORD_WAVES) void k_orders(Work w)
+__global__ __launch_bounds__(256) void k_gorder_exact(Work w)
 {
-	__shared__ OrdTile tiles[ORD_WAVES];
+	__shared__ WalkLds lds[4];
 	const int img = blockIdx.y;
 	if (!w.slow[img])
 		return;
-	const long nvb = (w.NCS + ORD_WAVES - 1) / ORD_WAVES;
+	const long nvb = (w.NCS + 3) / 4;
 	for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x)
-		orders_body(w, tiles, vb, img);
+		gorder_exact_body(w, lds[threadIdx.x >> 6].tok, vb * 4 + (threadIdx.x >> 6), img);
 }
 
-// ----------------------------------------------------------- k_orders_fast ---
-// The common case needs no 32-state machinery.  The order map of a token is
-// monotone, so every start state ends between the chains started at 0 and at
-// 31; over 64 tokens those two almost always meet (orders decay by 2 per small
-// value), and then the group's exit order is a constant, whatever it was
-// entered with.  One lane per 64-token group: walk the 0- and the 31-chain; if
-// they met, the NEXT group's entry order is known, and a second walk records
-// each token's order and bit offset.  Lane 0 only serves as the predecessor of
-// lane 1 (63 groups of output per wave).  If any pair of chains did not meet
-// the image is flagged and the exact hierarchical pass (k_lut ... k_orders)
-// redoes it.  Tokens go through LDS in tiles of QT per group, so that several
-// waves fit a SIMD.
-constexpr int FSUBS = 63;
-constexpr int QT = 32;                    // tokens per group staged at a time (128-byte rows; 8 -> 1440, 16 -> 970, 32 -> 870, 64 -> 1380 us per 16 frames)
-constexpr int QLANES = QT / 4;            // lanes that move one group's QT tokens (four each)
-constexpr int QSUBS = 64 / QLANES;        // groups per wave instruction
+// ------------------------------------------------------------------ k_emit ---
+// bits.h:58-78.  One lane per 64-token group: entry order and bit position are known, so the lane walks
+// its tokens once more, builds each code (vli.h:67-84: top-o zeros, a one, top remainder bits, then the
+// sign of the one that ended the run) and appends it to a 64-bit accumulator; full 32-bit words go to
+// an LDS window that covers the wave's stretch of the stream (OR: neighbouring lanes share their edge
+// words), the window goes to memory as whole words, only the wave's first and last word with atomicOr.
+// A break slot is followed by its segment's refinement block (k_refcopy fills it in): the lane notes
+// where it starts and skips it.  Words outside the window (a stretch made long by a refinement
+// block, or very long codes) are OR-ed into memory directly.
+constexpr int EWIN = 768;
 
-struct FastTile {
-	unsigned run[64][QT + 1];
-	unsigned char flag[64][QT + 4];
-	unsigned char ord[64][QT + 4];
-	unsigned short off[64][QT + 2];
+struct EmitLds {
+	unsigned tok[64 * WROW];
+	unsigned win[EWIN];
 };
 
-__global__ __launch_bounds__(256) void k_orders_fast(Work w)
+__global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_words)
 {
-	__shared__ FastTile tiles[4];
+	__shared__ EmitLds lds[4];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const long wave = (long)blockIdx.x * 4 + wv;
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
 	const long T = I.T;
-	const long nsub = (T + SUB - 1) / SUB;
-	if (wave * FSUBS >= nsub)
+	const long ngroups = (T + SUB - 1) / SUB;
+	if (wave * 64 >= ngroups)
 		return;
-	const unsigned *run = w.tok_run + img * w.TS;
-	const unsigned char *flag = w.tok_flag + img * w.TS;
+	const unsigned short *tok16 = w.tok16 + img * w.TS;
+	const unsigned *big = w.tok_big + img * w.TS;
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	FastTile &tile = tiles[wv];
-	const long S = wave * FSUBS - 1 + lane;          // this lane's 64-token group (lane 0: predecessor only)
-	const long tfirst = (wave * FSUBS - 1) * SUB;    // first token of the wave's window (-64 for wave 0)
-	// a lane moves four consecutive tokens of one group at a time: 16 bytes of runs, 4 bytes of flags
-	const int vsub = lane / QLANES, q4 = (lane % QLANES) * 4;
-	auto load_tile = [&](int qt) {
-#pragma unroll
-		for (int k = 0; k < 64 / QSUBS; ++k) {
-			const int sub = k * QSUBS + vsub;
-			const long t = tfirst + (long)sub * SUB + qt * QT + q4;   // multiple of 4, like every image's token base
-			uint4 r = make_uint4(0u, 0u, 0u, 0u);
-			unsigned f = F_VOID * 0x01010101u;
-			if (t >= 0 && t < T) {
-				r = *reinterpret_cast<const uint4 *>(run + t);
-				f = *reinterpret_cast<const unsigned *>(flag + t);
-				const long left = T - t;   // tokens past T are stale scratch
-				if (left < 4) {
-					r.w = 0u;
-					r.z = left > 2 ? r.z : 0u;
-					r.y = left > 1 ? r.y : 0u;
-					const unsigned keep = left > 2 ? 0x00ffffffu : left > 1 ? 0x0000ffffu : 0x000000ffu;
-					f = (f & keep) | ((F_VOID * 0x01010101u) & ~keep);
-				}
-			}
-			tile.run[sub][q4] = r.x;
-			tile.run[sub][q4 + 1] = r.y;
-			tile.run[sub][q4 + 2] = r.z;
-			tile.run[sub][q4 + 3] = r.w;
-			*reinterpret_cast<unsigned *>(&tile.flag[sub][q4]) = f;
+	unsigned *rows = lds[wv].tok, *win = lds[wv].win;
+	stage_tokens(rows, tok16, wave * CHUNK, T, lane);
+	for (int i = lane; i < EWIN; i += 64)
+		win[i] = 0u;
+	const long S = wave * 64 + lane;
+	const bool live = S < ngroups;
+	const int per = w.slow[img] ? 64 : FSUBS;
+	unsigned long long pos = 0;
+	int o = 0;
+	if (live) {
+		pos = w.chunk_base[img * w.NCS + S / per] + w.lane_bits[img * w.NCS * 64 + S];
+		o = w.grp_ord[img * w.NCS * 64 + S];
+	}
+	const long wbase = (long)(__shfl(pos, 0) >> 5);   // lane 0 is always live
+	unsigned *dst = out + img * out_words;
+	wave_sync();
+	auto put_word = [&](long wi, unsigned v) {
+		if (!v)
+			return;
+		const unsigned long rel = (unsigned long)(wi - wbase);
+		if (rel < (unsigned long)EWIN)
+			atomicOr(&win[rel], v);
+		else if (wi < out_words)
+			atomicOr(dst + wi, v);
+	};
+	long widx = (long)(pos >> 5);
+	int fill = (int)(pos & 31);
+	unsigned long long acc = 0;
+	auto append = [&](unsigned c, int n) {   // n <= 32 bits
+		acc |= (unsigned long long)c << fill;
+		fill += n;
+		if (fill >= 32) {
+			put_word(widx, (unsigned)acc);
+			++widx;
+			acc >>= 32;
+			fill -= 32;
 		}
 	};
-	int lo = 0, hi = 31;
-	for (int qt = 0; qt < SUB / QT; ++qt) {
-		load_tile(qt);
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int t = 0; t < QT; ++t) {
-			const unsigned f = tile.flag[lane][t];
-			const unsigned v = tile.run[lane][t];
-			lo = vli_step(lo, v, f & F_VOID);
-			hi = vli_step(hi, v, f & F_VOID);
-		}
-		__builtin_amdgcn_wave_barrier();
-	}
-	const bool valid = S >= 0 && S < nsub;
-	// A group whose two chains met leaves in a known order.  The rare other ones are resolved
-	// exactly as soon as their own entry order is known (one more walk, only in waves that have
-	// such a group); only if that chain of knowledge breaks (e.g. at the wave's predecessor lane)
-	// is the image handed to the exact pass.
-	int exitv = lo;
-	bool exit_known = lo == hi || !valid;
-	int o = 0;
-	bool entry_known = false;
-	for (int it = 0; it < 4; ++it) {
-		o = __shfl_up(exitv, 1);
-		entry_known = __shfl_up((int)exit_known, 1) != 0 && lane >= 1;
-		if (S == 0) {
-			o = I.order0;
-			entry_known = true;
-		}
-		const bool resolve = valid && !exit_known && entry_known;
-		if (!ballot64(resolve))
-			break;
-		int e = o;
-		for (int qt = 0; qt < SUB / QT; ++qt) {
-			load_tile(qt);
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int t = 0; t < QT; ++t)
-				e = vli_step(e, tile.run[lane][t], tile.flag[lane][t] & F_VOID);
-			__builtin_amdgcn_wave_barrier();
-		}
-		if (resolve) {
-			exitv = e;
-			exit_known = true;
-		}
-	}
-	if (ballot64(lane >= 1 && valid && !entry_known)) {
-		if (lane == 0)
-			atomicOr(w.slow + img, 1);
-		return;   // the exact pass takes the whole image
-	}
-	const bool produces = lane >= 1 && valid;
-	const long t0 = S * SUB;
-	unsigned tokbits = 0;
-	unsigned long long rawbits = 0;
-	unsigned char *ord = w.tok_ord + img * w.TS;
-	unsigned short *off = w.tok_off + img * w.TS;
-	for (int qt = 0; qt < SUB / QT; ++qt) {
-		load_tile(qt);
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int t = 0; t < QT; ++t) {
-			const unsigned f = tile.flag[lane][t];
-			tile.ord[lane][t] = (unsigned char)o;
-			tile.off[lane][t] = (unsigned short)tokbits;
-			if (!(f & F_VOID)) {
-				const int top = vli_top(o, tile.run[lane][t]);
-				tokbits += (unsigned)(2 * top - o + 1) + ((f & F_HAS_SIGN) ? 1u : 0u);
-				o = vli_next(top);
-			}
-			if ((f & F_BREAK) && produces)
-				rawbits += srefs[find_break_seg(btok, I.K, (unsigned)(t0 + qt * QT + t))];
-		}
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int k = 0; k < 64 / QSUBS; ++k) {
-			const int sub = k * QSUBS + vsub;
-			const long t = tfirst + (long)sub * SUB + qt * QT + q4;
-			if (sub < 1 || t >= T)
-				continue;
-			const unsigned o4 = *reinterpret_cast<const unsigned *>(&tile.ord[sub][q4]);
-			const unsigned f01 = *reinterpret_cast<const unsigned *>(&tile.off[sub][q4]);
-			const unsigned f23 = *reinterpret_cast<const unsigned *>(&tile.off[sub][q4 + 2]);
-			if (t + 4 <= T) {
-				*reinterpret_cast<unsigned *>(ord + t) = o4;
-				*reinterpret_cast<uint2 *>(off + t) = make_uint2(f01, f23);
-			} else {
-				for (int e = 0; e < (int)(T - t); ++e) {
-					ord[t + e] = tile.ord[sub][q4 + e];
-					off[t + e] = tile.off[sub][q4 + e];
-				}
-			}
-		}
-		__builtin_amdgcn_wave_barrier();
-	}
-	unsigned long long total;
-	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
-	if (produces)
-		w.lane_bits[img * w.NCS * 64 + S] = pre;
-	if (lane == 0)
-		w.chunk_bits[img * w.NCS + wave] = total;
-}
-
-// ------------------------------------------------------------------ k_emit ---
-// bits.h:58-78: one lane per four consecutive tokens, one wave per 256.  A token's position is
-// chunk base + its 64-token group's offset + its own offset (+ the refinement blocks of earlier
-// break tokens of the same group).  The four codes of a lane are adjacent in the stream unless a
-// break lies between them, so they are glued into one bit string first; the strings of a wave
-// are merged in an LDS window, and each stream word costs one global atomic per wave.
-
-constexpr int COMB = 192;      // words of the LDS window (typical: 256 tokens of ~4 bits = 32 words)
-constexpr int EMIT_TOK = 4;    // tokens per lane
-
-__global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_words)
-{
-	__shared__ unsigned comb[4][COMB];
-	const int lane = threadIdx.x & 63;
-	const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int img = blockIdx.y;
-	const ImgInfo &I = w.info[img];
-	const long T = I.T;
-	const long t0 = wave * (64 * EMIT_TOK) + lane * EMIT_TOK;   // multiple of 4, like the token arrays' bases
-	if (wave * (64 * EMIT_TOK) >= T)
-		return;
-	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
-	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
-	unsigned f4 = F_VOID * 0x01010101u, o4 = 0;
-	uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
-	uint2 off4 = make_uint2(0u, 0u);
-	unsigned long long gpos = 0;
-	if (t0 < T) {
-		f4 = *reinterpret_cast<const unsigned *>(w.tok_flag + img * w.TS + t0);
-		o4 = *reinterpret_cast<const unsigned *>(w.tok_ord + img * w.TS + t0);
-		r4 = *reinterpret_cast<const uint4 *>(w.tok_run + img * w.TS + t0);
-		off4 = *reinterpret_cast<const uint2 *>(w.tok_off + img * w.TS + t0);
-		const long left = T - t0;   // tokens past T are stale scratch
-		if (left < EMIT_TOK) {
-			const unsigned keep = left > 2 ? 0x00ffffffu : left > 1 ? 0x0000ffffu : 0x000000ffu;
-			f4 = (f4 & keep) | ((F_VOID * 0x01010101u) & ~keep);
-		}
-		const long group = t0 / SUB;
-		const long chunk = group / (w.slow[img] ? 64 : FSUBS);
-		gpos = w.chunk_base[img * w.NCS + chunk] + w.lane_bits[img * w.NCS * 64 + group];
-	}
-	const unsigned run[EMIT_TOK] = { r4.x, r4.y, r4.z, r4.w };
-	unsigned long long pos[EMIT_TOK], code[EMIT_TOK];
-	int len[EMIT_TOK];
-#pragma unroll
-	for (int e = 0; e < EMIT_TOK; ++e) {
-		const unsigned f = (f4 >> (8 * e)) & 255u;
-		pos[e] = gpos + (((e & 1) ? (e & 2 ? off4.y : off4.x) >> 16 : (e & 2 ? off4.y : off4.x)) & 0xffffu);
-		code[e] = 0;
-		len[e] = 0;
-		if (!(f & F_VOID)) {
-			const int o = (int)((o4 >> (8 * e)) & 255u);
-			const unsigned v = run[e];
+	const unsigned *my = rows + lane * WROW;
+	const long tb = S * SUB;
+	// one token, the general way: up to 64 code bits, break slots, escapes
+	auto slow_token = [&](unsigned tk, long t) {
+		if (!(tk & T_VOID)) {
+			const unsigned v = token_run(tk, big, t);
 			const int top = vli_top(o, v);
 			const int z = top - o;
-			code[e] = (1ull << z) | ((unsigned long long)(v + (1u << o) - (1u << top)) << (z + 1));
-			len[e] = z + 1 + top;
-			if (f & F_HAS_SIGN) {
-				code[e] |= (unsigned long long)(f & F_SIGN) << len[e];
-				++len[e];
+			const unsigned rem = v + (1u << o) - (1u << top);
+			unsigned long long code = (1ull << z) | ((unsigned long long)rem << (z + 1));
+			int len = z + 1 + top;
+			if (!(tk & T_NOSIGN)) {
+				code |= (unsigned long long)((tk >> 12) & 1u) << len;
+				++len;
 			}
+			o = vli_next(top);
+			append((unsigned)code, len < 32 ? len : 32);
+			if (len > 32)
+				append((unsigned)(code >> 32), len - 32);
 		}
-	}
-	// break tokens are followed by their segment's refinement block: later tokens of the same 64-token
-	// group move up by its size (k_orders_fast / k_orders counted it for the groups after that)
-	const unsigned brk4 = f4 & (F_BREAK * 0x01010101u);
-	bool split = false;   // a refinement block lies between this lane's tokens
-	if (ballot64(brk4 != 0)) {
+		if (tk & T_BREAK) {
+			// the segment's refinement block starts here (encode.c:84-93 follows the segment's first pass)
+			put_word(widx, (unsigned)acc);
+			acc = 0;
+			const long k = find_break_seg(btok, I.K, (unsigned)t);
+			const unsigned long long at = ((unsigned long long)widx << 5) + (unsigned)fill;
+			w.seg_rawoff[(long)img * MAX_SEGS + k] = at;
+			const unsigned long long next = at + srefs[k];
+			widx = (long)(next >> 5);
+			fill = (int)(next & 31);
+		}
+	};
+	// one token whose code is at most 16 bits (order <= 7, run < 128, not a break slot): no branches
+	auto code16 = [&](unsigned tk, unsigned &code, int &len) {
+		const unsigned s = (tk & T_RUN) + (1u << o);
+		const int top = 31 - __builtin_clz(s);
+		const int z = top - o;
+		const unsigned rem = s & ((1u << top) - 1u);
+		unsigned c = (rem << (z + 1)) | (1u << z);
+		int l = z + 1 + top;
+		c |= ((tk >> 12) & 1u) << l;
+		l += (tk & T_NOSIGN) ? 0 : 1;
+		const bool vd = (tk & T_VOID) != 0u;
+		code = vd ? 0u : c;
+		len = vd ? 0 : l;
+		o = vd ? o : (top >= 2 ? top - 2 : 0);
+	};
+	if (live) {
+#pragma unroll 2
+		for (int q = 0; q < 16; ++q) {
+			const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+			const unsigned xs[2] = { x2.x, x2.y };
 #pragma unroll
-		for (int e = 0; e < EMIT_TOK; ++e) {
-			unsigned long long bm = ballot64(((brk4 >> (8 * e)) & F_BREAK) != 0);
-			while (bm) {
-				const int j = __builtin_ctzll(bm);
-				bm &= bm - 1;
-				const long tb = wave * (64 * EMIT_TOK) + j * EMIT_TOK + e;   // the break token
-				const long k = find_break_seg(btok, I.K, (unsigned)tb);
-				const unsigned refs = srefs[k];
-#pragma unroll
-				for (int q = 0; q < EMIT_TOK; ++q) {
-					const long tq = t0 + q;
-					if (tq > tb && tq / SUB == tb / SUB) {
-						pos[q] += refs;
-						split = split || (refs != 0 && lane == j);
+			for (int h = 0; h < 2; ++h) {
+				const unsigned x = xs[h];
+				// run >= 128 (escapes too) or a break slot in the pair, or a high order: the general path
+				if ((x & (0x0f80u * 0x00010001u | T_BREAK * 0x00010001u)) != 0u || o > 7) {
+					slow_token(x & 0xffffu, tb + 4 * q + 2 * h);
+					slow_token(x >> 16, tb + 4 * q + 2 * h + 1);
+				} else {
+					unsigned c0, c1;
+					int l0, l1;
+					code16(x & 0xffffu, c0, l0);
+					code16(x >> 16, c1, l1);
+					acc |= (unsigned long long)(c0 | (c1 << l0)) << fill;   // fill < 32, the pair at most 32 bits
+					fill += l0 + l1;
+					if (fill >= 32) {
+						put_word(widx, (unsigned)acc);
+						++widx;
+						acc >>= 32;
+						fill -= 32;
 					}
 				}
 			}
 		}
-#pragma unroll
-		for (int e = 0; e < EMIT_TOK; ++e)   // every shift is in: where each break's refinement block starts
-			if ((brk4 >> (8 * e)) & F_BREAK)
-				w.seg_rawoff[(long)img * MAX_SEGS + find_break_seg(btok, I.K, (unsigned)(t0 + e))] = pos[e] + (unsigned)len[e];
+		put_word(widx, (unsigned)acc);
 	}
-	unsigned *cw = comb[threadIdx.x >> 6];
-	for (int i = lane; i < COMB; i += 64)
-		cw[i] = 0;
-	const long wbase = (long)(__shfl(pos[0], 0) >> 5);
-	__builtin_amdgcn_wave_barrier();
-	unsigned *dst = out + img * out_words;
-	auto put = [&](unsigned long long p, unsigned long long c) {   // up to 64 code bits at bit position p
-		const long w0 = (long)(p >> 5);
-		const int sh = (int)(p & 31);
-		const unsigned long long lo = c << sh;
-		const unsigned part[3] = { (unsigned)lo, (unsigned)(lo >> 32), sh ? (unsigned)(c >> (64 - sh)) : 0u };
-#pragma unroll
-		for (int q = 0; q < 3; ++q) {
-			const long wi = w0 + q;
-			if (!part[q])
-				continue;
-			if (wi - wbase < COMB)
-				atomicOr(cw + (wi - wbase), part[q]);
-			else if (wi < out_words)
-				atomicOr(dst + wi, part[q]);
-		}
-	};
-	const int total = len[0] + len[1] + len[2] + len[3];
-	// tokens of one 64-token group follow each other bit for bit (a lane never straddles two groups)
-	if (!split && total <= 64) {
-		unsigned long long c = 0;
-		int at = 0;
-#pragma unroll
-		for (int e = 0; e < EMIT_TOK; ++e) {
-			c |= len[e] ? code[e] << at : 0ull;
-			at += len[e];
-		}
-		if (total)
-			put(pos[0], c);
-	} else {
-#pragma unroll
-		for (int e = 0; e < EMIT_TOK; ++e)
-			if (len[e])
-				put(pos[e], code[e]);
-	}
-	__builtin_amdgcn_wave_barrier();
-	for (int i = lane; i < COMB; i += 64) {
-		const unsigned v = cw[i];
-		if (v && wbase + i < out_words)
-			atomicOr(dst + wbase + i, v);
+	// the window to memory: the words strictly inside the wave's stretch are its own
+	const long nlive = ngroups - wave * 64 < 64 ? ngroups - wave * 64 : 64;
+	const long endw = __shfl(widx, (int)nlive - 1);   // word of the last bit position (shared with whatever follows)
+	wave_sync();
+	for (int i = lane; i < EWIN; i += 64) {
+		const long wi = wbase + i;
+		if (wi - i + (i & ~63) > endw)   // uniform: nothing of this wave beyond
+			break;
+		if (wi > endw || wi >= out_words)
+			continue;
+		const unsigned v = win[i];
+		if (wi > wbase && wi < endw)
+			dst[wi] = v;
+		else if (v)
+			atomicOr(dst + wi, v);
 	}
 }
 
@@ -1343,7 +1714,7 @@ __global__ __launch_bounds__(1024) void k_bitscan(Work w, long capacity)
 	}
 }
 
-// The token and refinement writers OR their bits into the stream, so it has to start as zeros — but only
+// The token and refinement writers OR their edge words into the stream, so it has to start as zeros — but only
 // the words the stream will occupy (its length is known after k_bitscan), not the whole output stride;
 // the words k_plan filled with header, root image and plane counts stay.
 __global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, long out_words)
@@ -1365,80 +1736,53 @@ __global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, lon
 	}
 }
 
-// ---------------------------------------------------------------- k_refine ---
-// encode.c:84-93 second pass: raw magnitude bits of already-significant
-// coefficients, in coefficient order.  The k-th refinement coefficient of the
-// segment owns bit (segment block offset + k).  One wave per tile, all planes,
-// the tile's rows held in registers; the bits of one (tile, plane) are compacted
-// through an LDS staging row and merged into the stream with atomicOr.
-
-__global__ __launch_bounds__(256) void k_refine(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words)
+// --------------------------------------------------------------- k_refcopy ---
+// encode.c:84-93: a segment's raw refinement bits follow its first pass.  They wait in the staging
+// buffer, in coefficient order, each segment's block on a word boundary; their place in the stream
+// (seg_rawoff, noted by k_emit) is known now: a copy shifted by a constant number of bits per segment.
+__global__ __launch_bounds__(256) void k_refcopy(Work w, unsigned *out, long out_words)
 {
-	__shared__ unsigned stage[4][TILE / 32 + 2];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int tile = blockIdx.x * 4 + wv;
-	const int plane = blockIdx.y;
-	if (tile >= w.NT)
-		return;
-	const int img = plane / g.C, c = plane - img * g.C;
-	const ImgInfo &I = w.info[img];
-	int l = 0;
-	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
-		++l;
-	const int j = tile - g.tile_first[l];
-	const long ring1 = g.pixels[l + 1];
-	const long base = g.pixels[l] + (long)j * TILE;
-	const int *src = lin + (long)plane * g.total;
-	unsigned m[ROWS];
-	bool in[ROWS];
-#pragma unroll
-	for (int r = 0; r < ROWS; ++r) {
-		const long i = base + r * 64 + lane;
-		in[r] = i < ring1;
-		const int v = in[r] ? src[i] : 0;
-		m[r] = (unsigned)(v < 0 ? -v : v);
-	}
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int *sx = w.segidx + ((long)img * 48 + c * 16 + l) * MAX_PLANES;
-	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
-	unsigned *st = stage[wv];
+	const int img = blockIdx.y;
+	const int K = w.info[img].K;
+	const unsigned long long *sst = w.seg_stage + (long)img * (MAX_SEGS + 1);
+	const unsigned long long total = sst[K];
+	const unsigned *stage = w.stage + img * w.SW;
 	unsigned *dst = out + img * out_words;
-	const unsigned long long below = (1ull << lane) - 1ull;
-	for (int p = I.planes[c] - 2; p >= 0; --p) {   // the top plane of a channel has nothing to refine
-		const int k1 = sx[p];
-		if (!k1)
-			continue;
-		const int k = k1 - 1;
-		const int e = eb[k] + j;
-		const unsigned nref = w.ent_refs[img * w.ES + e];
-		if (!nref)
-			continue;
-		const unsigned long long bit0 = w.seg_rawoff[(long)img * MAX_SEGS + k] + (refscum[e] - refscum[eb[k]]);
-		if (lane < TILE / 32 + 2)
-			st[lane] = 0;
-		// each wave only touches its own stage row; wave-level ordering suffices
-		__builtin_amdgcn_wave_barrier();
-		const int shift = (int)(bit0 & 31);
-		unsigned done = 0;
-#pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			const bool refine = in[r] && (m[r] >> (p + 1)) != 0;
-			const unsigned long long rm = ballot64(refine);
-			if (refine && ((m[r] >> p) & 1u)) {
-				const unsigned pos = (unsigned)shift + done + (unsigned)__builtin_popcountll(rm & below);
-				atomicOr(&st[pos >> 5], 1u << (pos & 31));
+	for (unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total;
+		wi += (unsigned long long)gridDim.x * blockDim.x) {
+		int lo = 0, hi = K - 1;   // the segment whose block holds staging word wi: largest k with sst[k] <= wi
+		while (lo < hi) {
+			const int mid = (lo + hi + 1) >> 1;
+			if (sst[mid] <= wi)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		const int k = lo;
+		const unsigned long i = (unsigned long)(wi - sst[k]);
+		const unsigned n = w.seg_refs[(long)img * MAX_SEGS + k];
+		const unsigned long long D = w.seg_rawoff[(long)img * MAX_SEGS + k];
+		const int sh = (int)(D & 31);
+		const long d0 = (long)(D >> 5);
+		const unsigned long cw = ((unsigned long)n + 31) >> 5;            // staging words of the block
+		const unsigned long ndw = ((unsigned long)sh + n + 31) >> 5;      // stream words it touches
+		const unsigned cur = stage[wi];
+		const unsigned prev = i ? stage[wi - 1] : 0u;
+		const unsigned v = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
+		const long wd = d0 + (long)i;
+		if (wd < out_words) {
+			if (i == 0 || i == ndw - 1) {
+				if (v)
+					atomicOr(dst + wd, v);
+			} else {
+				dst[wd] = v;
 			}
-			done += (unsigned)__builtin_popcountll(rm);
 		}
-		__builtin_amdgcn_wave_barrier();
-		const long w0 = (long)(bit0 >> 5);
-		const int nwords = (int)((shift + nref + 31) >> 5);
-		if (lane < nwords) {
-			const unsigned val = st[lane];
-			if (val && w0 + lane < out_words)
-				atomicOr(dst + w0 + lane, val);
+		if (i == cw - 1 && ndw > cw && wd + 1 < out_words) {   // the block's tail spills into one more stream word
+			const unsigned v2 = cur >> (32 - sh);
+			if (v2)
+				atomicOr(dst + wd + 1, v2);
 		}
-		__builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -1447,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_refine(PackGeom g, const int *__restric
 // ------------------------------------------------------------------ driver ---
 
 enum {
-	SLOT_PK_CUM = 2, SLOT_PK_SMALL, SLOT_PK_ENT, SLOT_PK_TOKRUN, SLOT_PK_TOKB, SLOT_PK_LUT, SLOT_PK_CHUNK,
+	SLOT_PK_CUM = 2, SLOT_PK_SMALL, SLOT_PK_ENT, SLOT_PK_TOKBIG, SLOT_PK_TOK16, SLOT_PK_LUT, SLOT_PK_CHUNK, SLOT_PK_STAGE,
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1484,6 +1828,8 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
 	w.NGS = (w.NCS + GROUP - 1) / GROUP;
 	w.NCB = (w.ES + CARRY_BLOCK - 1) / CARRY_BLOCK;
+	// refinement bits: at most MAX_PLANES-1 per coefficient, every segment's block rounded up to a word
+	w.SW = (long)(((unsigned long long)C * (unsigned long long)(g.total - g.pixels[0]) * (MAX_PLANES - 1) + 31) / 32) + MAX_SEGS + 64;
 	const int nplanes = n * C;
 
 	// carve scratch
@@ -1500,6 +1846,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_eb = take(sizeof(int) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_ro = take(sizeof(unsigned long long) * (size_t)n * MAX_SEGS);
+		const size_t o_ss = take(sizeof(unsigned long long) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_bt = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_sx = take(sizeof(int) * (size_t)n * 48 * MAX_PLANES);
 		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
@@ -1513,6 +1860,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.seg_ebase = (int *)(small + o_eb);
 		w.seg_refs = (unsigned *)(small + o_sr);
 		w.seg_rawoff = (unsigned long long *)(small + o_ro);
+		w.seg_stage = (unsigned long long *)(small + o_ss);
 		w.brk_tok = (unsigned *)(small + o_bt);
 		w.segidx = (int *)(small + o_sx);
 		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
@@ -1542,13 +1890,11 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.carry_in = (unsigned *)(ent + o_ci);
 		w.ent_blk = (unsigned *)(ent + o_ek);
 
-		w.tok_run = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKRUN, sizeof(unsigned) * (size_t)n * w.TS);
-		char *tb = (char *)dwtx_scratch(ctx, SLOT_PK_TOKB, 4 * (size_t)n * w.TS);
-		if (!w.tok_run || !tb)
+		w.tok_big = (unsigned *)dwtx_scratch(ctx, SLOT_PK_TOKBIG, sizeof(unsigned) * (size_t)n * w.TS);
+		w.tok16 = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_TOK16, sizeof(unsigned short) * (size_t)n * w.TS);
+		w.stage = (unsigned *)dwtx_scratch(ctx, SLOT_PK_STAGE, sizeof(unsigned) * (size_t)n * w.SW);
+		if (!w.tok_big || !w.tok16 || !w.stage)
 			return DWTX_ERR_NOMEM;
-		w.tok_off = (unsigned short *)tb;
-		w.tok_flag = (unsigned char *)tb + 2 * (size_t)n * w.TS;
-		w.tok_ord = (unsigned char *)tb + 3 * (size_t)n * w.TS;
 
 		w.sublut = (unsigned char *)dwtx_scratch(ctx, SLOT_PK_LUT, (size_t)n * w.NCS * 64 * 32);
 		off = 0;
@@ -1556,6 +1902,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		const size_t o_gl = take((size_t)n * w.NGS * 32);
 		const size_t o_ce = take((size_t)n * w.NCS);
 		const size_t o_ge = take((size_t)n * w.NGS);
+		const size_t o_go = take((size_t)n * w.NCS * 64);
 		const size_t o_cb = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
 		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * w.NCS);
 		const size_t o_lb = take(sizeof(unsigned long long) * (size_t)n * w.NCS * 64);
@@ -1566,6 +1913,7 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 		w.glut = (unsigned char *)(ch + o_gl);
 		w.chunk_entry = (unsigned char *)(ch + o_ce);
 		w.group_entry = (unsigned char *)(ch + o_ge);
+		w.grp_ord = (unsigned char *)(ch + o_go);
 		w.chunk_bits = (unsigned long long *)(ch + o_cb);
 		w.chunk_base = (unsigned long long *)(ch + o_cs);
 		w.lane_bits = (unsigned long long *)(ch + o_lb);
@@ -1583,20 +1931,21 @@ extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int 
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
-	hipLaunchKernelGGL(k_tokens, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_stage_zero, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_code, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
-	hipLaunchKernelGGL(k_orders_fast, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_gorder, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
 	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
 	hipLaunchKernelGGL(k_lut, dim3(512, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_groups, dim3(64, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
-	hipLaunchKernelGGL(k_orders, dim3(512, n), dim3(64 * ORD_WAVES), 0, s, w);
+	hipLaunchKernelGGL(k_gorder_exact, dim3(512, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
 	hipLaunchKernelGGL(k_clear_stream, dim3((unsigned)((out_words / 4 + 256) / 256), n), dim3(256), 0, s, w, outw, out_words);
-	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / (64 * EMIT_TOK) + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
-	hipLaunchKernelGGL(k_refine, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w, outw, out_words);
+	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / CHUNK + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_refcopy, dim3(1024, n), dim3(256), 0, s, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
 	DWTX_HIP(hipMemcpyAsync(dev_info, w.info, sizeof(ImgInfo) * (size_t)n, hipMemcpyDeviceToDevice, s));
