@@ -50,7 +50,7 @@ constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
 constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
 constexpr int CH_BITS = 1 << CH_LOG2;
 constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
-constexpr int LINK_ROUNDS = 12;         // relaxation rounds: fewer leave more chunks unstitched, more let paths that ran through refinement blocks take over (both cost the walker; measured optimum 10-12)
+constexpr int LINK_ROUNDS = 2;          // work-list slots: round 1 (every chunk) fills the list of round 2 (k_link_fix)
 constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
 
 struct UnpackGeom {
@@ -398,19 +398,25 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 	return r;
 }
 
+// The chunk tables are laid out for the stream stride, the streams are usually much shorter: the chunk
+// kernels run a capped grid whose workgroups stride over the virtual blocks of 256 chunks that hold data.
+constexpr int CHUNK_GRID = 2048;
+
 __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y, img = vs / FAM;   // virtual stream = (image, family)
-	if (chunk >= w.nch[img])
-		return;
-	const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
-	// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
-	// number of bits apart cannot meet while the order stays 0: seed both parities.
-	int off = vs % FAM, o = 0;
-	const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
-	const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
-	w.exitX[vs * w.NCH + chunk] = out;
+	const long nch = w.nch[img];
+	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
+		if (chunk >= nch)
+			continue;
+		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+		// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
+		// number of bits apart cannot meet while the order stays 0: seed both parities.
+		int off = vs % FAM, o = 0;
+		const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
+		const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
+		w.exitX[vs * w.NCH + chunk] = out;
+	}
 }
 
 // One refinement round: parse chunk i from the state in which the previous
@@ -474,57 +480,81 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 	}
 }
 
-// round 1: every chunk
+// round 1: every chunk.  A chunk whose exit moved hands its successor to the work list and marks it
+// "listed" (in cg, which the scan only fills later).
 __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int vs = blockIdx.y;
-	bool moved = false;
-	if (chunk >= 1 && chunk < w.nch[vs / FAM])
-		moved = link_parse(w, streams, stream_stride, vs, chunk);
-	link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count + 2 * w.todo_round);
+	const long nch = w.nch[vs / FAM];
+	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
+		bool moved = false;
+		if (chunk >= 1 && chunk < nch)
+			moved = link_parse(w, streams, stream_stride, vs, chunk);
+		if (chunk < nch)
+			w.cg[vs * (w.NCH + 1) + chunk + 1] = moved ? 1u : 0u;
+		link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count + 2 * w.todo_round);
+	}
 }
 
-// later rounds: the chunks queued by the previous one
-__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
+// Round 1 leaves a list of chunks whose recorded entry state may no longer be what their predecessor
+// leaves in (a few percent).  Listed chunks that follow each other form a run; the thread of a run's first
+// chunk re-parses the whole run, each chunk from its predecessor's new exit, and goes on past the run while
+// the exit it arrives with differs from the entry the next chunk was recorded with (nearly always it agrees
+// at once).  It stops in front of the next run, which has its own thread: every chunk has one writer.  Where
+// two chains meet the records may disagree: k_scan_local only accepts a chunk whose entry equals its
+// predecessor's exit, and the walker parses what is not accepted itself.
+constexpr int FIX_MAX_CHAIN = 4096;
+
+__global__ __launch_bounds__(256) void k_link_fix(DWork w, const unsigned char *streams, long stream_stride)
 {
 	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
 		parts = gridDim.x / LINK_SHARDS;
-	const unsigned count = w.todo_count[round * w.todo_round + vs * LINK_SHARDS + shard];
-	const unsigned *list = w.todo[cur] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
-	for (unsigned q0 = part * blockDim.x; q0 < count; q0 += parts * blockDim.x) {   // uniform trip count per wave
-		const unsigned q = q0 + threadIdx.x;
-		bool moved = false;
-		long ch = 0;
-		if (q < count) {
-			ch = list[q];
-			moved = link_parse(w, streams, stream_stride, vs, ch);
+	const int img = vs / FAM;
+	const long nch = w.nch[img];
+	const unsigned count = w.todo_count[2 * w.todo_round + vs * LINK_SHARDS + shard];
+	const unsigned *list = w.todo[1] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
+	unsigned short *exitX = w.exitX + (long)vs * w.NCH, *entryE = w.entryE + (long)vs * w.NCH;
+	const unsigned *listed = w.cg + (long)vs * (w.NCH + 1);
+	for (unsigned q = part * blockDim.x + threadIdx.x; q < count; q += parts * blockDim.x) {
+		long ch = list[q];
+		if (ch >= nch || (ch >= 2 && listed[ch - 1]))
+			continue;   // inside a run: the thread of the run's first chunk comes through here
+		unsigned short in = exitX[ch - 1];
+		bool in_run = true;   // ch is a listed chunk of the run this thread owns
+		for (int step = 0; step < FIX_MAX_CHAIN; ++step) {
+			unsigned long long sym = 0;
+			unsigned tok = 0;
+			unsigned short out = 0xffff;
+			if (in != 0xffff) {
+				const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
+				int off = in & 0xff, o = in >> 8;
+				const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
+					++tok;
+					sym += (unsigned long long)run + 1ull;
+					return true;
+				});
+				if (alive)
+					out = (unsigned short)((off - CH_BITS) | (o << 8));
+			}
+			const long ci = vs * (w.NCH + 1) + ch;
+			entryE[ch] = in;
+			w.cs[ci] = sym;
+			w.ct[ci] = tok;
+			exitX[ch] = out;
+			if (ch + 1 >= nch)
+				break;
+			if (listed[ch + 1]) {
+				if (!in_run)
+					break;   // the next run's first chunk: its own thread re-parses it
+			} else {
+				// past the run: go on only while the successor's record was made from another state
+				if (entryE[ch + 1] == out || out == 0xffff)
+					break;
+				in_run = false;
+			}
+			in = out;
+			++ch;
 		}
-		link_push(w, vs, ch + 1, moved, w.todo[cur ^ 1], w.todo_count + (round + 1) * w.todo_round);
-	}
-}
-
-// a chunk's record is usable iff it was made from the state its predecessor now leaves in
-__global__ __launch_bounds__(256) void k_link_final(DWork w)
-{
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int vs = blockIdx.y;
-	const long nch = w.nch[vs / FAM];
-	if (chunk > nch)
-		return;
-	const long ci = vs * (w.NCH + 1) + chunk;
-	if (chunk == 0 || chunk == nch) {   // chunk 0 has no predecessor; element nch is the scan sentinel
-		w.cs[ci] = 0;
-		w.ct[ci] = 0;
-		w.cg[ci] = chunk == 0 ? 1u : 0u;
-		return;
-	}
-	const unsigned short prev = w.exitX[vs * w.NCH + chunk - 1];
-	const bool bad = prev == 0xffff || w.entryE[vs * w.NCH + chunk] != prev || w.exitX[vs * w.NCH + chunk] == 0xffff;
-	w.cg[ci] = bad ? 1u : 0u;
-	if (bad) {   // never hopped over; keep the prefix sums small and monotone
-		w.cs[ci] = 0;
-		w.ct[ci] = 0;
 	}
 }
 
@@ -598,43 +628,78 @@ __device__ __forceinline__ void quad_store(const DWork &w, long at, const Quad &
 	*reinterpret_cast<uint4 *>(w.cg + at) = q.g;
 }
 
+// A chunk's record is usable iff it was made from the state its predecessor now leaves in: cg = 1 marks
+// the others (never hopped over; their counts are zeroed to keep the prefix sums small and monotone).  Chunk
+// 0 has no predecessor; element nch is the scan's sentinel.  The flag is left in entryE for k_scan_add.
+constexpr int SCAN_GRID = 1024;
+
 __global__ __launch_bounds__(256) void k_scan_local(DWork w)
 {
 	__shared__ Tri wsum[4];
-	const int img = blockIdx.y;   // virtual stream
-	const long n = w.NCH + 1, used = w.nch[img / FAM] + 1;
-	if ((long)blockIdx.x * SCAN_BLOCK >= used)
-		return;
-	const long i = (long)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
-	const bool in = i < used;
-	Quad q;
-	q.s01 = q.s23 = make_ulonglong2(0ull, 0ull);
-	q.t = q.g = make_uint4(0u, 0u, 0u, 0u);
-	if (in)
-		q = quad_load(w, img * n + i);
-	const Tri mine = { q.s01.x + q.s01.y + q.s23.x + q.s23.y, q.t.x + q.t.y + q.t.z + q.t.w, q.g.x + q.g.y + q.g.z + q.g.w };
-	Tri total;
-	const Tri pre = block_scan_tri(mine, wsum, total);
-	if (in) {
-		Quad o;
-		o.s01.x = pre.s;
-		o.s01.y = o.s01.x + q.s01.x;
-		o.s23.x = o.s01.y + q.s01.y;
-		o.s23.y = o.s23.x + q.s23.x;
-		o.t.x = pre.t;
-		o.t.y = o.t.x + q.t.x;
-		o.t.z = o.t.y + q.t.y;
-		o.t.w = o.t.z + q.t.z;
-		o.g.x = pre.g;
-		o.g.y = o.g.x + q.g.x;
-		o.g.z = o.g.y + q.g.y;
-		o.g.w = o.g.z + q.g.z;
-		quad_store(w, img * n + i, o);
-	}
-	if (threadIdx.x == 0) {
-		w.part_s[img * w.NB + blockIdx.x] = total.s;
-		w.part_t[img * w.NB + blockIdx.x] = total.t;
-		w.part_g[img * w.NB + blockIdx.x] = total.g;
+	const int vs = blockIdx.y;   // virtual stream
+	const long n = w.NCH + 1, nch = w.nch[vs / FAM], used = nch + 1;
+	unsigned short *exitX = w.exitX + (long)vs * w.NCH, *entryE = w.entryE + (long)vs * w.NCH;
+	for (long vb = blockIdx.x; vb * SCAN_BLOCK < used; vb += gridDim.x) {
+		const long i = vb * SCAN_BLOCK + 4 * threadIdx.x;
+		const bool in = i < used;
+		Quad q;
+		q.s01 = q.s23 = make_ulonglong2(0ull, 0ull);
+		q.t = q.g = make_uint4(0u, 0u, 0u, 0u);
+		if (in) {
+			q = quad_load(w, vs * n + i);
+			unsigned long long *sv[4] = { &q.s01.x, &q.s01.y, &q.s23.x, &q.s23.y };
+			unsigned *tv[4] = { &q.t.x, &q.t.y, &q.t.z, &q.t.w }, *gv[4] = { &q.g.x, &q.g.y, &q.g.z, &q.g.w };
+			unsigned short prev = i >= 1 && i - 1 < nch ? exitX[i - 1] : (unsigned short)0xffff;
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const long c = i + e;
+				unsigned flag;
+				if (c == 0 || c >= nch) {
+					flag = c == 0 ? 1u : 0u;
+					*sv[e] = 0;
+					*tv[e] = 0;
+				} else {
+					const unsigned short x = exitX[c];
+					const bool bad = prev == 0xffff || entryE[c] != prev || x == 0xffff;
+					flag = bad ? 1u : 0u;
+					if (bad) {
+						*sv[e] = 0;
+						*tv[e] = 0;
+					}
+					prev = x;
+				}
+				if (c == 0)
+					prev = nch > 0 ? exitX[0] : (unsigned short)0xffff;
+				*gv[e] = flag;
+				if (c < nch)
+					entryE[c] = (unsigned short)flag;
+			}
+		}
+		const Tri mine = { q.s01.x + q.s01.y + q.s23.x + q.s23.y, q.t.x + q.t.y + q.t.z + q.t.w, q.g.x + q.g.y + q.g.z + q.g.w };
+		Tri total;
+		const Tri pre = block_scan_tri(mine, wsum, total);
+		if (in) {
+			Quad o;
+			o.s01.x = pre.s;
+			o.s01.y = o.s01.x + q.s01.x;
+			o.s23.x = o.s01.y + q.s01.y;
+			o.s23.y = o.s23.x + q.s23.x;
+			o.t.x = pre.t;
+			o.t.y = o.t.x + q.t.x;
+			o.t.z = o.t.y + q.t.y;
+			o.t.w = o.t.z + q.t.z;
+			o.g.x = pre.g;
+			o.g.y = o.g.x + q.g.x;
+			o.g.z = o.g.y + q.g.y;
+			o.g.w = o.g.z + q.g.z;
+			quad_store(w, vs * n + i, o);
+		}
+		if (threadIdx.x == 0) {
+			w.part_s[vs * w.NB + vb] = total.s;
+			w.part_t[vs * w.NB + vb] = total.t;
+			w.part_g[vs * w.NB + vb] = total.g;
+		}
+		__syncthreads();   // wsum is reused by the next virtual block
 	}
 }
 
@@ -663,53 +728,54 @@ __global__ __launch_bounds__(256) void k_scan_parts(DWork w)
 	}
 }
 
+// adds the block offsets and files the unjoined chunks: the one with rank r (= cg[i], exclusive prefix) goes to breaks[r]
 __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 {
-	const int img = blockIdx.y;   // virtual stream
-	const long n = w.NCH + 1;
-	const long i = (long)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
-	if (i >= w.nch[img / FAM] + 1 || blockIdx.x == 0)   // the first block's prefixes are final already
-		return;
-	const unsigned long long ps = w.part_s[img * w.NB + blockIdx.x];
-	const unsigned pt = w.part_t[img * w.NB + blockIdx.x], pg = w.part_g[img * w.NB + blockIdx.x];
-	Quad q = quad_load(w, img * n + i);
-	q.s01.x += ps;
-	q.s01.y += ps;
-	q.s23.x += ps;
-	q.s23.y += ps;
-	q.t.x += pt;
-	q.t.y += pt;
-	q.t.z += pt;
-	q.t.w += pt;
-	q.g.x += pg;
-	q.g.y += pg;
-	q.g.z += pg;
-	q.g.w += pg;
-	quad_store(w, img * n + i, q);
-}
-
-// compact list of the unjoined chunks: the one with rank r (= cg[i], exclusive prefix) goes to slot r
-__global__ __launch_bounds__(256) void k_breaks(DWork w)
-{
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int vs = blockIdx.y;
-	if (chunk >= w.nch[vs / FAM])
-		return;
-	const unsigned *cg = w.cg + (long)vs * (w.NCH + 1);
-	if (cg[chunk + 1] != cg[chunk])
-		w.breaks[(long)vs * w.NCH + cg[chunk]] = (unsigned)chunk;
+	const int vs = blockIdx.y;   // virtual stream
+	const long n = w.NCH + 1, nch = w.nch[vs / FAM], used = nch + 1;
+	const unsigned short *flags = w.entryE + (long)vs * w.NCH;
+	unsigned *breaks = w.breaks + (long)vs * w.NCH;
+	for (long vb = blockIdx.x; vb * SCAN_BLOCK < used; vb += gridDim.x) {
+		const long i = vb * SCAN_BLOCK + 4 * threadIdx.x;
+		if (i >= used)
+			continue;
+		const unsigned long long ps = w.part_s[vs * w.NB + vb];
+		const unsigned pt = w.part_t[vs * w.NB + vb], pg = w.part_g[vs * w.NB + vb];
+		Quad q = quad_load(w, vs * n + i);
+		q.s01.x += ps;
+		q.s01.y += ps;
+		q.s23.x += ps;
+		q.s23.y += ps;
+		q.t.x += pt;
+		q.t.y += pt;
+		q.t.z += pt;
+		q.t.w += pt;
+		q.g.x += pg;
+		q.g.y += pg;
+		q.g.z += pg;
+		q.g.w += pg;
+		if (vb)   // the first block's prefixes are final already
+			quad_store(w, vs * n + i, q);
+		const unsigned g4[4] = { q.g.x, q.g.y, q.g.z, q.g.w };
+#pragma unroll
+		for (int e = 0; e < 4; ++e)
+			if (i + e < nch && flags[i + e])
+				breaks[g4[e]] = (unsigned)(i + e);
+	}
 }
 
 // the tokens of every chunk (piece) the walker did not set itself -> symbits
 __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int img = blockIdx.y;
 	const int nh = w.nhops[img];
+	const long nchunks = w.nch[img];
 	const unsigned *hf = w.hop_first + (long)img * w.MAX_HOPS, *hl = w.hop_last + (long)img * w.MAX_HOPS;
+	for (long vblock = blockIdx.x; vblock * blockDim.x < nchunks; vblock += gridDim.x) {
+	const long chunk = vblock * blockDim.x + threadIdx.x;
 	// records are in stream order; the search is done once per workgroup (uniform, scalar loads) for
 	// its first chunk, every thread then steps forward to its own chunk
-	const unsigned first_chunk = (unsigned)((long)blockIdx.x * blockDim.x);
+	const unsigned first_chunk = (unsigned)(vblock * blockDim.x);
 	int lo = 0, hi = nh;   // first h with hl[h] >= first_chunk
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
@@ -783,15 +849,16 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 	if (lo < nh && hf[lo] <= first_chunk && hl[lo] >= first_chunk + blockDim.x - 1 && (lo + 1 >= nh || hf[lo + 1] > first_chunk + blockDim.x - 1)) {
 		if (mine)
 			piece(lo);
-		return;
+		continue;
 	}
 	if (!mine)
-		return;
+		continue;
 	int h = lo;
 	while (h < nh && hl[h] < (unsigned)chunk)
 		++h;
 	for (; h < nh && hf[h] <= (unsigned)chunk; ++h)
 		piece(h);
+	}
 }
 
 // --------------------------------------------------------------- k_tokenize ---
@@ -1230,12 +1297,27 @@ __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 }
 
 // --------------------------------------------------------------- k_apply_all ---
-// One wave per tile, all planes in registers: 1024 coefficients start at zero;
-// for every plane (descending) an insignificant coefficient reads pass-1 symbol
-// #(tile rank + its position among the insignificant ones) from the bitmap, a
-// significant one reads refinement bit #(index in ring - that count) straight
-// from the stream.  The tile is written once, already in two's complement
-// (decode.c:102-117 process()).
+// One wave per tile, lane L owns coefficients 16L .. 16L+15, all planes in registers: 1024 coefficients
+// start at zero; for every plane (descending) the lane's still insignificant coefficients are CONSECUTIVE
+// pass-1 symbols (tile rank + insignificant coefficients in the lanes before: one DPP scan) and its
+// significant ones CONSECUTIVE refinement bits (index in ring - that count), so each lane fetches one
+// 32-bit window of the symbol bitmap and one of the stream's refinement block and hands the bits out to its
+// 16 coefficients in order.  The tile is written once, already in two's complement (decode.c:102-117 process()).
+
+struct __attribute__((packed, aligned(4))) Int4S {
+	int x, y, z, w;
+};
+
+__device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
+{
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+	return v;
+}
 
 __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
 {
@@ -1254,66 +1336,88 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	const int j = tile - g.tile_first[l];
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)j * TILE;
+	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const int first = 16 * lane;
+	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;   // this lane's coefficients
+	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
 	const unsigned *sym = w.symbits + img * w.BW;
 	const unsigned *stream = (const unsigned *)(streams + img * stream_stride);
-	const int left = (int)(ring1 - base < TILE ? ring1 - base : TILE) - lane;   // row r holds a coefficient iff 64r < left
-	const unsigned idx0 = (unsigned)j * TILE + (unsigned)lane;                  // ring index of this lane's row-0 coefficient
-	unsigned mag[ROWS];
-	unsigned neg = 0;   // bit r: the coefficient of row r is negative
-	bool anysig = false;   // uniform: some coefficient of the tile is significant
+	const long stream_words = stream_stride >> 2;
+	unsigned mag[16];
 #pragma unroll
-	for (int r = 0; r < ROWS; ++r)
-		mag[r] = 0;
+	for (int i = 0; i < 16; ++i)
+		mag[i] = 0;
+	unsigned neg = 0;                       // bit i: coefficient i of this lane is negative
+	unsigned ins = (1u << nv) - 1u;         // bit i: coefficient i is still insignificant (nv = 16 at most)
+	if (nv == 16)
+		ins = 0xffffu;
+	bool anysig = false;                    // uniform: some coefficient of the tile is significant
 	for (int p = I.planes[c] - 1; p >= 0; --p) {
 		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
 		if (!k1)
 			continue;
 		const int k = k1 - 1;
-		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
-		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
 		const unsigned tr = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
 		// nothing to do while the tile is all zeros and this plane adds no ones to it (k_count's flag):
 		// on fine levels that is every plane above the noise floor
 		if (!(tr >> 31) && !anysig)
 			continue;
 		anysig = true;
-		unsigned rank = tr & 0x7fffffffu;
-		// Both sources are read as one 32-bit word per coefficient and plane: the symbol bitmap (two bits
-		// per symbol; a segment's symbols start on a word boundary) while the coefficient is
-		// insignificant, the stream's refinement block once it is significant.  The address is the
-		// bitmap base plus a lane offset; refinement reads add the uniform distance to their block.
-		const unsigned *sbase = sym + (w.seg_symbase[(long)img * MAX_SEGS + k] >> 4);
-		const unsigned b2s = (unsigned)(b2 & 31);
-		const long rdelta = (const char *)(stream + (b2 >> 5)) - (const char *)sbase;
-		// sel: bits 0-4 shift, bit 5 "pass-1 symbol", bit 6 "has a bit in this plane"
-		unsigned word[ROWS], sel[ROWS];
-#pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			const bool in = 64 * r < left;
-			const bool ns = in && mag[r] == 0;
-			const unsigned long long nm = ballot64(ns);
-			const unsigned r1 = rank + (unsigned)popc_below(nm);
-			rank += (unsigned)__builtin_popcountll(nm);
-			const unsigned r2 = idx0 + 64u * r - r1;   // significant coefficients before this one
-			const bool rf = in && !ns && r2 < n2done;
-			const unsigned pb = b2s + r2;
-			const unsigned wi = ns ? r1 >> 4 : rf ? pb >> 5 : 0u;
-			sel[r] = ns ? 96u | ((r1 & 15u) << 1) : rf ? 64u | (pb & 31u) : 0u;
-			word[r] = *(const unsigned *)((const char *)sbase + (rf ? rdelta : 0l) + 4l * wi);
+		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
+		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
+		const unsigned ci = (unsigned)__builtin_popcount(ins);
+		const unsigned nb = wave_incl_add_u(ci) - ci;                 // insignificant coefficients in the lanes before
+		const unsigned r1 = (tr & 0x7fffffffu) + nb;                   // pass-1 symbol index of this lane's first insignificant one
+		const unsigned r2 = (unsigned)j * TILE + (unsigned)vb - r1;    // refinement index of its first significant one
+		// symbols: two bits each (one flag, sign); a segment's symbols start on a word boundary
+		unsigned s32 = 0;
+		if (ci) {
+			const unsigned *sp = sym + (w.seg_symbase[(long)img * MAX_SEGS + k] >> 4) + (r1 >> 4);
+			const unsigned sh = (r1 & 15u) * 2u;
+			const unsigned w0 = sp[0], w1 = sh ? sp[1] : 0u;
+			s32 = __builtin_amdgcn_alignbit(w1, w0, sh);
+		}
+		// refinement bits that the stream still holds for this lane (a truncated stream ends inside some block)
+		const unsigned cs = (unsigned)nv - ci;
+		const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
+		unsigned r16 = 0;
+		if (avail) {
+			const unsigned long long pb = b2 + r2;
+			const long wi = (long)(pb >> 5);
+			const unsigned sh = (unsigned)(pb & 31);
+			const unsigned x0 = stream[wi], x1 = sh + avail > 32u && wi + 1 < stream_words ? stream[wi + 1] : 0u;
+			r16 = __builtin_amdgcn_alignbit(x1, x0, sh) & ((1u << avail) - 1u);   // avail <= 16
 		}
 #pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			const unsigned bits = word[r] >> (sel[r] & 31u);
-			const unsigned bit = bits & (sel[r] >> 6);
-			mag[r] |= bit << p;
-			neg |= ((bits >> 1) & bit & (sel[r] >> 5)) << r;   // the sign follows a pass-1 one (decode.c:80-85)
+		for (int i = 0; i < 16; ++i) {
+			const bool isz = (ins >> i) & 1u;
+			const unsigned sb = s32 & 3u;
+			const unsigned one = isz ? sb & 1u : 0u;
+			const unsigned bit = isz ? one : r16 & 1u;
+			mag[i] |= bit << p;
+			neg |= (one & (sb >> 1)) << i;      // the sign follows a pass-1 one (decode.c:80-85)
+			ins ^= one << i;
+			s32 = isz ? s32 >> 2 : s32;
+			r16 = isz ? r16 : r16 >> 1;
 		}
 	}
-	int *dst = lin + (long)plane * g.lin_stride + base;
+	int *dst = lin + (long)plane * g.lin_stride + base + first;
+	if (nvalid == TILE) {
 #pragma unroll
-	for (int r = 0; r < ROWS; ++r)
-		if (64 * r < left)
-			dst[r * 64 + lane] = ((neg >> r) & 1u) ? -(int)mag[r] : (int)mag[r];
+		for (int q = 0; q < 4; ++q) {
+			Int4S v;
+			v.x = ((neg >> (4 * q)) & 1u) ? -(int)mag[4 * q] : (int)mag[4 * q];
+			v.y = ((neg >> (4 * q + 1)) & 1u) ? -(int)mag[4 * q + 1] : (int)mag[4 * q + 1];
+			v.z = ((neg >> (4 * q + 2)) & 1u) ? -(int)mag[4 * q + 2] : (int)mag[4 * q + 2];
+			v.w = ((neg >> (4 * q + 3)) & 1u) ? -(int)mag[4 * q + 3] : (int)mag[4 * q + 3];
+			*reinterpret_cast<Int4S *>(dst + 4 * q) = v;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			if (i < nv)
+				dst[i] = ((neg >> i) & 1u) ? -(int)mag[i] : (int)mag[i];
+	}
 }
 
 // tile_nonsig starts as the tile's coefficient count
@@ -1533,19 +1637,15 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	auto pre = [&](hipStream_t st, int i0, int cnt) -> int {
 		const DWork h = slice(i0);
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
-		const dim3 cg((unsigned)((w.NCH + 1 + 255) / 256), cnt * FAM);
+		const unsigned cblocks = (unsigned)((w.NCH + 1 + 255) / 256);
+		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * FAM);
 		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
-		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills list 1 for round 2
-		int cur = 1;
-		for (int r = 2; r <= LINK_ROUNDS; ++r) {
-			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
-			cur ^= 1;
-		}
-		hipLaunchKernelGGL(k_link_final, cg, dim3(256), 0, st, h);
-		hipLaunchKernelGGL(k_scan_local, dim3((unsigned)w.NB, cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills the list of chunks to redo
+		hipLaunchKernelGGL(k_link_fix, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride);
+		const unsigned sblocks = (unsigned)(w.NB < SCAN_GRID ? w.NB : SCAN_GRID);
+		hipLaunchKernelGGL(k_scan_local, dim3(sblocks, cnt * FAM), dim3(256), 0, st, h);
 		hipLaunchKernelGGL(k_scan_parts, dim3(cnt * FAM), dim3(256), 0, st, h);
-		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)w.NB, cnt * FAM), dim3(256), 0, st, h);
-		hipLaunchKernelGGL(k_breaks, dim3((unsigned)((w.NCH + 255) / 256), cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_add, dim3(sblocks, cnt * FAM), dim3(256), 0, st, h);
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
 	};
@@ -1555,7 +1655,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));   // the bitmap is clear
 		hipLaunchKernelGGL(k_tokenize, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
 			lin + (size_t)i0 * C * g.lin_stride, cnt);
-		hipLaunchKernelGGL(k_hopbits, dim3((unsigned)((w.NCH + 255) / 256), cnt), dim3(256), 0, st, h, str, (long)stream_stride);
+		const unsigned hblocks = (unsigned)((w.NCH + 255) / 256);
+		hipLaunchKernelGGL(k_hopbits, dim3(hblocks < CHUNK_GRID ? hblocks : CHUNK_GRID, cnt), dim3(256), 0, st, h, str, (long)stream_stride);
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
 	};
