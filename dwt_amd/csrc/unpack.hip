@@ -50,7 +50,7 @@ constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
 constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
 constexpr int CH_BITS = 1 << CH_LOG2;
 constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
-constexpr int LINK_ROUNDS = 2;          // work-list slots: round 1 (every chunk) fills the list of round 2 (k_link_fix)
+constexpr int LINK_ROUNDS = 12;         // relaxation rounds: fewer leave more chunks unstitched, more let paths that ran through refinement blocks take over (both cost the walker; measured optimum 10-12)
 constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
 
 struct UnpackGeom {
@@ -480,8 +480,7 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 	}
 }
 
-// round 1: every chunk.  A chunk whose exit moved hands its successor to the work list and marks it
-// "listed" (in cg, which the scan only fills later).
+// round 1: every chunk; a chunk whose exit moved hands its successor to the work list
 __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride)
 {
 	const int vs = blockIdx.y;
@@ -490,71 +489,28 @@ __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *
 		bool moved = false;
 		if (chunk >= 1 && chunk < nch)
 			moved = link_parse(w, streams, stream_stride, vs, chunk);
-		if (chunk < nch)
-			w.cg[vs * (w.NCH + 1) + chunk + 1] = moved ? 1u : 0u;
 		link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count + 2 * w.todo_round);
 	}
 }
 
-// Round 1 leaves a list of chunks whose recorded entry state may no longer be what their predecessor
-// leaves in (a few percent).  Listed chunks that follow each other form a run; the thread of a run's first
-// chunk re-parses the whole run, each chunk from its predecessor's new exit, and goes on past the run while
-// the exit it arrives with differs from the entry the next chunk was recorded with (nearly always it agrees
-// at once).  It stops in front of the next run, which has its own thread: every chunk has one writer.  Where
-// two chains meet the records may disagree: k_scan_local only accepts a chunk whose entry equals its
-// predecessor's exit, and the walker parses what is not accepted itself.
-constexpr int FIX_MAX_CHAIN = 4096;
-
-__global__ __launch_bounds__(256) void k_link_fix(DWork w, const unsigned char *streams, long stream_stride)
+// later rounds: the chunks queued by the previous one.  Several percent after round 1, then slowly fewer: inside
+// the raw refinement blocks (most of a stream's bits) every parse is arbitrary and the paths there keep moving;
+// those records are never used, so the rounds are simply cut off (LINK_ROUNDS)
+__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
 {
 	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
 		parts = gridDim.x / LINK_SHARDS;
-	const int img = vs / FAM;
-	const long nch = w.nch[img];
-	const unsigned count = w.todo_count[2 * w.todo_round + vs * LINK_SHARDS + shard];
-	const unsigned *list = w.todo[1] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
-	unsigned short *exitX = w.exitX + (long)vs * w.NCH, *entryE = w.entryE + (long)vs * w.NCH;
-	const unsigned *listed = w.cg + (long)vs * (w.NCH + 1);
-	for (unsigned q = part * blockDim.x + threadIdx.x; q < count; q += parts * blockDim.x) {
-		long ch = list[q];
-		if (ch >= nch || (ch >= 2 && listed[ch - 1]))
-			continue;   // inside a run: the thread of the run's first chunk comes through here
-		unsigned short in = exitX[ch - 1];
-		bool in_run = true;   // ch is a listed chunk of the run this thread owns
-		for (int step = 0; step < FIX_MAX_CHAIN; ++step) {
-			unsigned long long sym = 0;
-			unsigned tok = 0;
-			unsigned short out = 0xffff;
-			if (in != 0xffff) {
-				const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
-				int off = in & 0xff, o = in >> 8;
-				const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
-					++tok;
-					sym += (unsigned long long)run + 1ull;
-					return true;
-				});
-				if (alive)
-					out = (unsigned short)((off - CH_BITS) | (o << 8));
-			}
-			const long ci = vs * (w.NCH + 1) + ch;
-			entryE[ch] = in;
-			w.cs[ci] = sym;
-			w.ct[ci] = tok;
-			exitX[ch] = out;
-			if (ch + 1 >= nch)
-				break;
-			if (listed[ch + 1]) {
-				if (!in_run)
-					break;   // the next run's first chunk: its own thread re-parses it
-			} else {
-				// past the run: go on only while the successor's record was made from another state
-				if (entryE[ch + 1] == out || out == 0xffff)
-					break;
-				in_run = false;
-			}
-			in = out;
-			++ch;
+	const unsigned count = w.todo_count[round * w.todo_round + vs * LINK_SHARDS + shard];
+	const unsigned *list = w.todo[cur] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
+	for (unsigned q0 = part * blockDim.x; q0 < count; q0 += parts * blockDim.x) {   // uniform trip count per wave
+		const unsigned q = q0 + threadIdx.x;
+		bool moved = false;
+		long ch = 0;
+		if (q < count) {
+			ch = list[q];
+			moved = link_parse(w, streams, stream_stride, vs, ch);
 		}
+		link_push(w, vs, ch + 1, moved, w.todo[cur ^ 1], w.todo_count + (round + 1) * w.todo_round);
 	}
 }
 
@@ -1641,7 +1597,11 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * FAM);
 		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
 		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills the list of chunks to redo
-		hipLaunchKernelGGL(k_link_fix, dim3(LINK_SHARDS * 4, cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride);
+		int cur = 1;
+		for (int r = 2; r <= LINK_ROUNDS; ++r) {   // the lists shrink: fewer workgroups per shard after the first rounds
+			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * (r <= 3 ? 4 : 1), cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
+			cur ^= 1;
+		}
 		const unsigned sblocks = (unsigned)(w.NB < SCAN_GRID ? w.NB : SCAN_GRID);
 		hipLaunchKernelGGL(k_scan_local, dim3(sblocks, cnt * FAM), dim3(256), 0, st, h);
 		hipLaunchKernelGGL(k_scan_parts, dim3(cnt * FAM), dim3(256), 0, st, h);
