@@ -292,8 +292,9 @@ __device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, 
 			const int top = o + z;
 			if (z + top + 2 <= 32) {
 				len = z + top + 2;
-				run = ((w32 >> (z + 1)) & ((1u << top) - 1u)) + (1u << top) - (1u << o);
-				neg = (w32 >> (z + 1 + top)) & 1u;
+				// top remainder bits after the one, plus 2^top - 2^o = (2^z - 1) << o (bit-field extract / mask instructions)
+				run = __builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o);
+				neg = __builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u);
 				next = top >= 2 ? top - 2 : 0;
 			} else {
 				const unsigned long long lo64 = d[seg] | ((unsigned long long)d[seg + 1] << 32);
