@@ -390,13 +390,32 @@ __device__ __forceinline__ const uint8_t *fwd_base(SrcTag<Rgb8>, const LevelArgs
 	return a.src8 + (plane / 3) * a.src_ps;   // src_ps = bytes per interleaved image, spitch = bytes per row
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with an L2 of its own): with the plain mapping the
+// strips left and right of a strip — whose edge sectors it also loads as halo — sit on other XCDs and those
+// sectors come from HBM a second time.  Remap so that an XCD owns a contiguous run of strips (whole bands of
+// rows): workgroup D of a plane works on strip (D mod 8) * (N/8) + D / 8.  Speed only; any mapping is correct.
+__device__ __forceinline__ void xcd_strip(int &bx, int &by)
+{
+	bx = blockIdx.x;
+	by = blockIdx.y;
+	const int n = gridDim.x * gridDim.y;
+	if ((n & 7) == 0) {
+		const int d = bx + gridDim.x * by;
+		const int s = (d & 7) * (n >> 3) + (d >> 3);
+		by = s / gridDim.x;
+		bx = s - by * gridDim.x;
+	}
+}
+
 template <typename SrcT>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int q = blockIdx.x * 64 + lane;
-	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int q = bx * 64 + lane;
+	const int j0 = (by * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
@@ -523,8 +542,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int qd = blockIdx.x * INV_QUADS - 1 + lane;
-	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int qd = bx * INV_QUADS - 1 + lane;
+	const int j0 = (by * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
@@ -636,8 +657,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int qd = blockIdx.x * INV_QUADS - 1 + lane;
-	const int j0 = (blockIdx.y * WAVES + wv) * a.rpw;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int qd = bx * INV_QUADS - 1 + lane;
+	const int j0 = (by * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);

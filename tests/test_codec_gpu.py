@@ -338,3 +338,40 @@ def test_image_sizes_beyond_int_indexing_are_refused(ctx):
     for W, H in ((50000, 50000), (65536, 32768), (65537, 8), (8, 7)):
         rc = ctx.lib.dwtx_encode_device(ctx.h, tiny.data_ptr(), W, H, 1, 1, 0, tiny.data_ptr(), 64, info.data_ptr())
         assert rc == -3, (W, H, rc)
+
+
+def test_config_c_1024_frames_of_1080p_rgb_in_one_call(ctx):
+    """BASELINE.json configs[2] at its real batch size: 1024 x 1920x1080 RGB (6.4 G samples, past 2^32) through
+    dwtx_encode_device / dwtx_decode_device in ONE call each: every frame comes back bit for bit, sampled
+    frames carry the oracle's bytes (frame 0 also the real reference's golden)."""
+    import torch
+
+    n, W, H, Cn = 1024, 1920, 1080, 3
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 * (1 << 30):
+        pytest.skip("needs about 230 GiB of free HBM")
+    pix = ctx.synth_pixels(n, H, W, Cn, seed0=0, kind=0)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    host_lens = lens.cpu().numpy()
+    assert host_lens.min() > 1 << 20 and host_lens.max() < streams.shape[1]
+    rec = G["c1920x1080"]
+    s0 = streams[0, : int(host_lens[0])].cpu().numpy().tobytes()
+    assert len(s0) == rec["dwt_len"] and sha(s0) == rec["dwt_sha256"]
+    for i in (1, 255, 256, 511, 777, 1023):
+        want, _ = orc.encode(orc.synth(W, H, Cn, i, 0))
+        assert streams[i, : int(host_lens[i])].cpu().numpy().tobytes() == want, i
+    # a stride that fits the streams (the encoder's output stride is a worst-case bound; the decoder's
+    # chunk tables are laid out per stride)
+    stride = (int(host_lens.max()) + 64 + 7) // 8 * 8
+    tight = streams[:, :stride].contiguous()
+    del streams, info
+    torch.cuda.empty_cache()
+    out, infos = ctx.decode_device(tight, lens, W, H, Cn)
+    assert all(i.status == 0 and not i.truncated for i in infos)
+    ok = True
+    for i0 in range(0, n, 64):
+        ok = ok and bool(torch.equal(out[i0:i0 + 64].view(-1, H, W, Cn), pix[i0:i0 + 64]))
+    assert ok
+    del out, tight, pix
+    torch.cuda.empty_cache()

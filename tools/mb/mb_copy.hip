@@ -7,6 +7,18 @@ __global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ a, uint4
 	for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256)
 		b[i] = a[i];
 }
+// the same copy with 8-byte and 4-byte accesses per lane (calibration of FETCH_SIZE / WRITE_SIZE for narrower accesses:
+// the inverse lifting kernel loads its subbands 8 bytes per lane)
+__global__ __launch_bounds__(256) void copy8(const uint2 *__restrict__ a, uint2 *__restrict__ b, long n8)
+{
+	for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256)
+		b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void copy4(const unsigned *__restrict__ a, unsigned *__restrict__ b, long n4)
+{
+	for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+		b[i] = a[i];
+}
 // row-strip pattern of the lifting kernels: a wave walks down `rows` rows of a pitch-`pitch16` image, 1 KB per row
 __global__ __launch_bounds__(256) void copy_strips(const uint4 *__restrict__ a, uint4 *__restrict__ b, int pitch16, int rows, int h)
 {
@@ -42,6 +54,8 @@ int main()
 	};
 	for (int blocks : {2048, 8192, 32768})
 		time("copy16 grid-stride blocks=" + std::to_string(blocks), [&] { hipLaunchKernelGGL(copy16, dim3(blocks), dim3(256), 0, 0, a, b, bytes / 16); });
+	time("copy8 grid-stride blocks=8192", [&] { hipLaunchKernelGGL(copy8, dim3(8192), dim3(256), 0, 0, (const uint2 *)a, (uint2 *)b, bytes / 8); });
+	time("copy4 grid-stride blocks=8192", [&] { hipLaunchKernelGGL(copy4, dim3(8192), dim3(256), 0, 0, (const unsigned *)a, (unsigned *)b, bytes / 4); });
 	for (int rows : {16, 64, 256})
 		time("copy_strips rows/wave=" + std::to_string(rows), [&] { hipLaunchKernelGGL(copy_strips, dim3(1024 / 64, 4096 / (4 * rows), 16), dim3(256), 0, 0, a, b, 1024, rows, 4096); });
 	time("hipMemcpyAsync D2D", [&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
