@@ -40,9 +40,11 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 		if ((rc = dwtx_transformation_fwd(ctx, b, a, W, H, n * C)))            // encode.c:159
 			return rc;
 	}
-	if ((rc = dwtx_linearization(ctx, a, b, W, H, n * C)))                 // encode.c:160
+	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
+	const unsigned sq = getenv("DWTX_NO_SQUARE_TILES") ? 0u : dwtx_square_levels(W, H);
+	if ((rc = dwtx_linearization_ex(ctx, a, b, W, H, n * C, sq)))
 		return rc;
-	return dwtx_encode_planes(ctx, a, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
+	return dwtx_encode_planes_ex(ctx, a, b, sq, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
 }
 
 // streams (device) -> pixels (device).  Image i is written densely (ow*oh*C bytes)
@@ -74,7 +76,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 			return DWTX_ERR_NOMEM;
 	}
 	// reconstruction -> inverse transform -> pixels for images [first, first+count), queued on ctx->stream
-	auto finish = [&](int first, int count) -> int {
+	auto finish = [&](int first, int count, unsigned fused) -> int {
 		const dwtx_decode_info &I = host_info[first];
 		const int lo = I.level + 1;                                          // decode.c:251
 		const int ow = g.widths[lo], oh = g.heights[lo];
@@ -97,7 +99,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		int *pyr = b + plane_ints * C * first;
 		int *img = a + plane_ints * C * first;   // lin is dead once reconstructed
 		int r;
-		if ((r = dwtx_reconstruction(ctx, pyr, lin, miss, lo, W, H, C, count)))              // decode.c:257
+		if ((r = dwtx_reconstruction_ex(ctx, pyr, lin, miss, lo, W, H, C, count, fused)))    // decode.c:257 (the rest of it)
 			return r;
 		if (dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
 			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count);   // decode.c:258-264
@@ -112,23 +114,23 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		return DWTX_OK;
 	};
 	// called by the decoder for each part of the batch as soon as its coefficients are on their way
-	auto part = [&](int first, int count) -> int {
+	auto part = [&](int first, int count, unsigned fused) -> int {
 		bool uniform = true;
 		for (int i = first; i < first + count; ++i)
 			uniform = uniform && !host_info[i].status && host_info[i].level == host_info[first].level &&
 				memcmp(host_info[i].missing, host_info[first].missing, sizeof(host_info[first].missing)) == 0;
 		if (uniform)
-			return finish(first, count);
-		for (int i = first; i < first + count; ++i) {
+			return finish(first, count, fused);
+		for (int i = first; i < first + count; ++i) {   // (a fused part's images all come out whole; their square levels are in the pyramid already)
 			int r;
-			if (!host_info[i].status && (r = finish(i, 1)))
+			if (!host_info[i].status && (r = finish(i, 1, fused)))
 				return r;
 		}
 		return DWTX_OK;
 	};
 	using Part = decltype(part);
-	return dwtx_decode_planes_ex(ctx, a, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info,
-		[](void *user, int first, int count) { return (*(Part *)user)(first, count); }, &part);
+	return dwtx_decode_planes_ex(ctx, a, b, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info,
+		[](void *user, int first, int count, unsigned fused) { return (*(Part *)user)(first, count, fused); }, &part);
 }
 
 // ---- host-buffer wrappers (what the CLIs call) ---------------------------------

@@ -72,10 +72,21 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
 int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n);   // C = 3: YCoCg-R fused too (image.h:52-65)
 int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n);   // C = 3: image.h:39-50 fused too
 
+// Tiles straight from / to the pyramid (hilbert_dev.h): ring levels that are full power-of-two squares (bit l of the
+// mask) need no linearised copy — the entropy stage reads (pack.hip) / writes (unpack.hip) their 32x32 squares itself.
+unsigned dwtx_square_levels(int W, int H);
+int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels);
+int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing, int levels_out, int W, int H,
+	int C, int n, unsigned skip_levels);
+int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, int W, int H, int C, int n,
+	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info);
+
 // unpack.hip: dwtx_decode_planes with a host callback per finished part of the batch (see there)
-int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
+// `pyr` (optional): pyramid planes [n*C][H][W]; for parts of the batch that decode at full resolution the tiles of
+// the full-square ring levels are written there (bias included) and `done` is told which levels (fused_levels).
+int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8_t *streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
-	int (*done)(void *user, int first, int count), void *user);
+	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user);
 
 // The wave's lanes for which `pred` holds.  (HIP's __ballot() takes an int: the condition would be turned
 // into 0/1 in a register and compared again — two extra instructions per use in the ballot-heavy kernels.)

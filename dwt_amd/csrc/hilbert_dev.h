@@ -1,0 +1,166 @@
+// hilbert_dev.h — the Hilbert curve inside aligned 32x32 squares (hilbert.h:15-34), shared by the
+// linearisation kernels and by the entropy-stage kernels that read / write coefficient tiles straight
+// from / to the wavelet pyramid.
+//
+// The curve visits every aligned 2^k x 2^k square contiguously.  Inside a 32x32 square it is the same
+// for every square up to the flips and swaps its position on the coarser levels imposes: a table
+// holds the first five levels of the recursion for the 1024 points of a square (x | y << 8); what
+// the levels above do to a square's points is one swap and two XOR masks, uniform per square.
+//
+// For a ring level whose outer square is a full power of two n x n (n >= 64: widths[l+1] ==
+// heights[l+1] == lengths[l+1]), ring index r of encode.c:46-56 is curve index n*n/4 + r with no point
+// skipped, so the entropy stage's tile j (ring indices 1024j .. 1024j+1023) IS the 32x32 square with
+// curve block index n*n/4096 + j.
+#pragma once
+
+#include "dwtx_internal.h"
+
+namespace {
+
+constexpr int BLK_LOG2 = 5;                 // 32x32 squares
+constexpr int SQ_PITCH = 33;                // LDS pitch of a staged square (conflict-free rows and columns)
+
+struct HilbertLow {
+	unsigned short xy[1 << (2 * BLK_LOG2)];
+};
+
+constexpr HilbertLow make_hilbert_low()
+{
+	HilbertLow t{};
+	for (unsigned i = 0; i < (1u << (2 * BLK_LOG2)); ++i) {
+		unsigned x = 0, y = 0, d = i;
+		for (unsigned s = 1; s < (1u << BLK_LOG2); s <<= 1) {
+			const unsigned rx = (d >> 1) & 1u;
+			const unsigned ry = (d ^ rx) & 1u;
+			if (rx && !ry) {
+				x ^= s - 1;
+				y ^= s - 1;
+			}
+			if (!ry) {
+				const unsigned tmp = x;
+				x = y;
+				y = tmp;
+			}
+			x |= rx ? s : 0u;
+			y |= ry ? s : 0u;
+			d >>= 2;
+		}
+		t.xy[i] = (unsigned short)(x | (y << 8));
+	}
+	return t;
+}
+
+__device__ const HilbertLow HILBERT_LOW = make_hilbert_low();
+
+// x = (sw ? yl : xl) ^ mx, y = (sw ? xl : yl) ^ my  (OR-ing in a level's bit is an XOR too, the bit is still clear)
+struct SquareMap {
+	bool sw;
+	unsigned mx, my;
+};
+
+__device__ __forceinline__ SquareMap square_map(int n, unsigned sq)   // square index = curve index >> 10, n >= 32
+{
+	SquareMap m = { false, 0u, 0u };
+	for (unsigned s = 1u << BLK_LOG2; s < (unsigned)n; s <<= 1) {
+		const unsigned rx = (sq >> 1) & 1u;
+		const unsigned ry = (sq ^ rx) & 1u;
+		if (rx && !ry) {
+			m.mx ^= s - 1;
+			m.my ^= s - 1;
+		}
+		if (!ry) {
+			const unsigned t = m.mx;
+			m.mx = m.my;
+			m.my = t;
+			m.sw = !m.sw;
+		}
+		m.mx ^= rx ? s : 0u;
+		m.my ^= ry ? s : 0u;
+		sq >>= 2;
+	}
+	return m;
+}
+
+__device__ __forceinline__ void hilbert_in_square(const SquareMap &m, int i, int &xo, int &yo)
+{
+	const unsigned e = HILBERT_LOW.xy[i];
+	const unsigned xl = e & 255u, yl = e >> 8;
+	xo = (int)((m.sw ? yl : xl) ^ m.mx);
+	yo = (int)((m.sw ? xl : yl) ^ m.my);
+}
+
+// Lanes of ONE wave hand data to each other through LDS: the wave's DS operations execute in order, so all
+// that is needed is that the compiler keeps the accesses on their side of this point.
+__device__ __forceinline__ void sq_wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS position (row * SQ_PITCH + column inside the square) of the 16 curve points 16*lane .. 16*lane+15 of the
+// square `m` describes
+__device__ __forceinline__ void square_positions16(const SquareMap &m, int lane, unsigned (&pos)[16])
+{
+	const unsigned a = m.mx & 31u, b = m.my & 31u;
+	const uint4 e0 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane);
+	const uint4 e1 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane + 8);
+	const unsigned e[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		const unsigned w = (e[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+		const unsigned xl = w & 31u, yl = (w >> 8) & 31u;
+		const unsigned x5 = (m.sw ? yl : xl) ^ a, y5 = (m.sw ? xl : yl) ^ b;
+		pos[k] = y5 * SQ_PITCH + x5;
+	}
+}
+
+// Tile j of a full-square ring level (outer side n) of one plane: the wave reads the 32x32 square as whole
+// 128-byte rows, stages it in LDS (32*SQ_PITCH words) and every lane picks up its 16 consecutive curve points.
+__device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr, int ppitch, int n, int j, int lane,
+	unsigned *lds, int (&val)[16])
+{
+	const SquareMap m = square_map(n, (unsigned)(((unsigned long)n * (unsigned long)n) >> 12) + (unsigned)j);
+	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
+#pragma unroll
+	for (int it = 0; it < 4; ++it) {
+		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+		const int4 v = *reinterpret_cast<const int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4);
+		unsigned *t = lds + row * SQ_PITCH + c4;
+		t[0] = (unsigned)v.x;
+		t[1] = (unsigned)v.y;
+		t[2] = (unsigned)v.z;
+		t[3] = (unsigned)v.w;
+	}
+	unsigned pos[16];
+	square_positions16(m, lane, pos);
+	sq_wave_sync();
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+		val[k] = (int)lds[pos[k]];
+	sq_wave_sync();   // the caller may reuse the LDS words
+}
+
+// the inverse: 16 consecutive curve points per lane -> the pyramid's 32x32 square
+__device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int ppitch, int n, int j, int lane, unsigned *lds,
+	const int (&val)[16])
+{
+	const SquareMap m = square_map(n, (unsigned)(((unsigned long)n * (unsigned long)n) >> 12) + (unsigned)j);
+	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
+	unsigned pos[16];
+	square_positions16(m, lane, pos);
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+		lds[pos[k]] = (unsigned)val[k];
+	sq_wave_sync();
+#pragma unroll
+	for (int it = 0; it < 4; ++it) {
+		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+		const unsigned *t = lds + row * SQ_PITCH + c4;
+		*reinterpret_cast<int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4) = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+	}
+	sq_wave_sync();
+}
+
+} // namespace
+

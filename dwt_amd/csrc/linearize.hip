@@ -13,14 +13,13 @@
 // rank.  One workgroup handles one block for one plane; lanes take consecutive
 // d so the linear side of the copy is a coalesced stream and the pyramid side
 // touches a compact 32x32 tile.
-#include "dwtx_internal.h"
+#include "hilbert_dev.h"
 
 #include <stdlib.h>
 #include <string.h>
 
 namespace {
 
-constexpr int BLK_LOG2 = 5;                 // 32x32 squares
 constexpr int THREADS = 256;
 
 struct LinGeom {
@@ -51,80 +50,6 @@ __device__ __forceinline__ void hilbert_d2xy(int n, unsigned d, int &xo, int &yo
 	}
 	xo = (int)x;
 	yo = (int)y;
-}
-
-// The curve inside an aligned 32x32 square is the same for every square up to the flips and
-// swaps its position on the coarser levels imposes.  Table: the first five levels of the
-// recursion for the 1024 points of a square (x | y << 8); the remaining levels only see the
-// square's index, which is uniform per workgroup, and act on all of its points alike.
-struct HilbertLow {
-	unsigned short xy[1 << (2 * BLK_LOG2)];
-};
-
-constexpr HilbertLow make_hilbert_low()
-{
-	HilbertLow t{};
-	for (unsigned i = 0; i < (1u << (2 * BLK_LOG2)); ++i) {
-		unsigned x = 0, y = 0, d = i;
-		for (unsigned s = 1; s < (1u << BLK_LOG2); s <<= 1) {
-			const unsigned rx = (d >> 1) & 1u;
-			const unsigned ry = (d ^ rx) & 1u;
-			if (rx && !ry) {
-				x ^= s - 1;
-				y ^= s - 1;
-			}
-			if (!ry) {
-				const unsigned tmp = x;
-				x = y;
-				y = tmp;
-			}
-			x |= rx ? s : 0u;
-			y |= ry ? s : 0u;
-			d >>= 2;
-		}
-		t.xy[i] = (unsigned short)(x | (y << 8));
-	}
-	return t;
-}
-
-__device__ const HilbertLow HILBERT_LOW = make_hilbert_low();
-
-// What the levels above a 32x32 square do to its points is one swap and two XOR masks (OR-ing in a
-// level's bit is an XOR too, the bit is still clear): x = (sw ? yl : xl) ^ mx, y = (sw ? xl : yl) ^ my.
-struct SquareMap {
-	bool sw;
-	unsigned mx, my;
-};
-
-__device__ __forceinline__ SquareMap square_map(int n, unsigned sq)   // square index = curve index >> 10, n >= 32
-{
-	SquareMap m = { false, 0u, 0u };
-	for (unsigned s = 1u << BLK_LOG2; s < (unsigned)n; s <<= 1) {
-		const unsigned rx = (sq >> 1) & 1u;
-		const unsigned ry = (sq ^ rx) & 1u;
-		if (rx && !ry) {
-			m.mx ^= s - 1;
-			m.my ^= s - 1;
-		}
-		if (!ry) {
-			const unsigned t = m.mx;
-			m.mx = m.my;
-			m.my = t;
-			m.sw = !m.sw;
-		}
-		m.mx ^= rx ? s : 0u;
-		m.my ^= ry ? s : 0u;
-		sq >>= 2;
-	}
-	return m;
-}
-
-__device__ __forceinline__ void hilbert_in_square(const SquareMap &m, int i, int &xo, int &yo)
-{
-	const unsigned e = HILBERT_LOW.xy[i];
-	const unsigned xl = e & 255u, yl = e >> 8;
-	xo = (int)((m.sw ? yl : xl) ^ m.mx);
-	yo = (int)((m.sw ? xl : yl) ^ m.my);
 }
 
 __device__ __forceinline__ int overlap(int lo, int len, int bound)
@@ -213,11 +138,13 @@ constexpr int PTS = 4;   // curve points per thread (1024 / THREADS)
 template <bool INVERSE>
 __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__restrict__ blockbase,
 	int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch,
-	const int *__restrict__ missing, int C, int nplanes)
+	const int *__restrict__ missing, int C, int nplanes, unsigned skip_levels)
 {
 	__shared__ int wcount[THREADS / 64];
 	const int b = blockIdx.x;
 	const int l = level_of_block(g, b);
+	if ((skip_levels >> l) & 1u)
+		return;   // the entropy stage reads / writes this level's tiles in the pyramid itself
 	const int lb = b - g.blk_first[l];
 	const int n = g.lengths[l + 1];
 	const int pl2 = g.blk_pts_log2[l];
@@ -426,7 +353,29 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 	ctx->plans = nullptr;
 }
 
+unsigned dwtx_square_levels(int W, int H)
+{
+	dwtx_geom g;
+	if (dwtx_geometry(&g, W, H) || (W & 3))
+		return 0u;
+	unsigned mask = 0;
+	for (int l = 0; l < g.levels; ++l) {
+		const int n = g.lengths[l + 1];
+		if (n >= 64 && g.widths[l + 1] == n && g.heights[l + 1] == n)
+			mask |= 1u << l;
+	}
+	return mask;
+}
+
+int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels);
+
 extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes)
+{
+	return dwtx_linearization_ex(ctx, lin, pyr, W, H, nplanes, 0u);
+}
+
+// skip_levels: ring levels that are NOT copied (their tiles are read from the pyramid by the entropy stage)
+int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels)
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -439,13 +388,23 @@ extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *py
 	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
 		g.widths[0], g.heights[0], lin, ps, const_cast<int *>(pyr), ps, W);
 	hipLaunchKernelGGL(k_ring_copy<false>, dim3(p->nblocks, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
-		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes);
+		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
 
+int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
+	int levels_out, int W, int H, int C, int n, unsigned skip_levels);
+
 extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
 	int levels_out, int W, int H, int C, int n)
+{
+	return dwtx_reconstruction_ex(ctx, pyr, lin, dev_missing, levels_out, W, H, C, n, 0u);
+}
+
+// skip_levels: ring levels the decoder's entropy stage has already written into the pyramid (with their bias)
+int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
+	int levels_out, int W, int H, int C, int n, unsigned skip_levels)
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || (C != 1 && C != 3) || n < 1 || n * C > 65535)
 		return DWTX_ERR_ARG;
@@ -465,7 +424,7 @@ extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *l
 	if (levels_out > 0) {
 		g.levels = levels_out;   // only rings 0..levels_out-1 are rebuilt
 		hipLaunchKernelGGL(k_ring_copy<true>, dim3(g.blk_first[levels_out], dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
-			ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes);
+			ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels);
 	}
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;

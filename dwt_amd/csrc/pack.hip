@@ -43,7 +43,7 @@
 //             through an LDS window of the wave's stretch of the stream.
 //   k_refcopy refinement blocks from the staging buffer to their place behind
 //             each segment's tokens (a shifted copy).
-#include "dwtx_internal.h"
+#include "hilbert_dev.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +68,9 @@ constexpr unsigned T_RUN = 0x0fffu, T_ESC = 0x0fffu, T_SIGN = 1u << 12, T_BREAK 
 struct PackGeom {
 	int levels, C, W, H;
 	long total;
+	const int *pyr;        // wavelet pyramid of the same planes (pitch W), or null
+	unsigned sq_levels;    // ring levels whose tiles are read from the pyramid's 32x32 squares instead of `lin` (hilbert_dev.h)
+	int side[DWTX_MAX_LEVELS + 1];          // outer side of ring level l (lengths[l+1])
 	int pixels[DWTX_MAX_LEVELS + 1];
 	int tile_first[DWTX_MAX_LEVELS + 1];   // tile_first[levels] = tiles per plane
 };
@@ -180,15 +183,41 @@ __device__ __forceinline__ void seg_unpack(int d, int &c, int &l, int &p)
 	p = (d >> 8) - 1;
 }
 
+// The 16 coefficients of lane L (ring indices 16L .. 16L+15 of tile j of ring level l): from the linearised
+// plane, or — for the levels flagged in sq_levels — from the pyramid's 32x32 square that holds exactly this tile.
+struct __attribute__((packed, aligned(4))) Int4U {
+	int x, y, z, w;
+};
+
+__device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__restrict__ lin, int plane, int l, int j, int lane, int nvalid,
+	int nv, unsigned *lds, int (&val)[16])
+{
+	if ((g.sq_levels >> l) & 1u) {   // uniform
+		load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], j, lane, lds, val);
+		return;
+	}
+	const int *src = lin + (long)plane * g.total + g.pixels[l] + (long)j * TILE + 16 * lane;
+	if (nvalid == TILE) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + 4 * q);
+			val[4 * q] = v4.x;
+			val[4 * q + 1] = v4.y;
+			val[4 * q + 2] = v4.z;
+			val[4 * q + 3] = v4.w;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			val[i] = i < nv ? src[i] : 0;
+	}
+}
+
 // ------------------------------------------------------------------ k_hist ---
 // Lane L owns coefficients 16L .. 16L+15 of the tile (four 16-byte loads).  With t = number of magnitude
 // bits, adding 0x1111.. << 4t to a 64-bit register counts "t <= q" for all q = 0..15 at once in its
 // nibbles (two registers of eight coefficients each: a nibble holds up to 8); the lane totals, widened
 // to 16-bit fields, are summed over the wave with DPP adds.
-
-struct __attribute__((packed, aligned(4))) Int4U {
-	int x, y, z, w;
-};
 
 __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
 {
@@ -203,24 +232,11 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)(tile - g.tile_first[l]) * TILE;
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
-	const int *src = lin + (long)plane * g.total + base;
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
+	__shared__ unsigned sq_lds[4][32 * SQ_PITCH];
 	int val[16];
-	if (nvalid == TILE) {
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + first + 4 * q);
-			val[4 * q] = v4.x;
-			val[4 * q + 1] = v4.y;
-			val[4 * q + 2] = v4.z;
-			val[4 * q + 3] = v4.w;
-		}
-	} else {
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			val[i] = i < nv ? src[first + i] : 0;
-	}
+	load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, sq_lds[threadIdx.x >> 6], val);
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 	unsigned long long Ra = 0, Rb = 0;
 	unsigned mx = 0;
@@ -863,27 +879,14 @@ __global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict_
 	const long base = g.pixels[l] + (long)j * TILE;
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
 	const int P = I.planes[c] < MAX_PLANES ? I.planes[c] : MAX_PLANES;
-	const int *src = lin + (long)plane * g.total + base;
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;   // this lane's coefficients
 	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
 
-	// ---- the coefficients, once ----
+	// ---- the coefficients, once (the class table's LDS words stage a pyramid square meanwhile) ----
+	static_assert(sizeof(L.tab) >= sizeof(unsigned) * 32 * SQ_PITCH, "the class table doubles as the square's staging area");
 	int val[16];
-	if (nvalid == TILE) {
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + first + 4 * q);
-			val[4 * q] = v4.x;
-			val[4 * q + 1] = v4.y;
-			val[4 * q + 2] = v4.z;
-			val[4 * q + 3] = v4.w;
-		}
-	} else {
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			val[i] = i < nv ? src[first + i] : 0;
-	}
+	load_tile16(g, lin, plane, l, j, lane, nvalid, nv, L.tab, val);
 	// per-plane bookkeeping of this tile's entries (lanes 0..15 take a plane each): three dependent look-ups
 	// whose results are only needed after the first passes over the coefficients — they stay in registers till then
 	unsigned my_tokbase = 0;
@@ -1799,16 +1802,31 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int H, int C, int n, long capacity,
 	uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
 {
+	return dwtx_encode_planes_ex(ctx, lin, nullptr, 0u, W, H, C, n, capacity, out, out_stride, dev_info);
+}
+
+// pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
+// 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
+int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, int W, int H, int C, int n,
+	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
+{
 	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
 		return DWTX_ERR_ARG;
 	DWTX_CHECK_DIMS(W, H);
+	if (sq_levels && (!pyr || (sq_levels & ~dwtx_square_levels(W, H)) || ((uintptr_t)pyr & 15)))
+		return DWTX_ERR_ARG;
 	PackGeom g;
 	{
 		int lengths[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS];
 		g.levels = dwtx_compute_lengths(lengths, pixels, widths, heights, W, H, DWTX_MIN_LEN);
 		for (int l = 0; l <= g.levels; ++l)
 			g.pixels[l] = pixels[l];
+		for (int l = 0; l < g.levels; ++l)
+			g.side[l] = lengths[l + 1];
+		g.side[g.levels] = 0;
 	}
+	g.pyr = pyr;
+	g.sq_levels = sq_levels;
 	g.C = C;
 	g.W = W;
 	g.H = H;

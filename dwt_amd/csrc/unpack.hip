@@ -36,7 +36,7 @@
 //               (decode.c:102-117).
 // Batches run as two halves on two streams (the second also clears `symbits`
 // while the first builds its tables); see dwtx_decode_planes_ex.
-#include "dwtx_internal.h"
+#include "hilbert_dev.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -60,6 +60,9 @@ struct UnpackGeom {
 	int pixels[DWTX_MAX_LEVELS + 1];
 	int tile_first[DWTX_MAX_LEVELS + 1];
 	int levels_max;                           // decode.c:163-171 PIXELS cap
+	int *pyr;                                 // pyramid planes (pitch W) that take the tiles of the levels in sq_levels, or null
+	unsigned sq_levels;                       // ring levels written as 32x32 squares of the pyramid instead of into `lin` (hilbert_dev.h)
+	int side[DWTX_MAX_LEVELS + 1];            // outer side of ring level l (lengths[l+1])
 };
 
 struct DecInfo {
@@ -1358,6 +1361,23 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			r16 = isz ? r16 : r16 >> 1;
 		}
 	}
+	if ((g.sq_levels >> l) & 1u) {
+		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
+		// with the dead-zone bias of planes that were never decoded (decode.c:51-58)
+		__shared__ unsigned sq_lds[4][32 * SQ_PITCH];
+		const int m = I.missing[c * 16 + l] - 2;
+		const int bias = m >= 0 ? 1 << m : 0;
+		int val[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			int v = ((neg >> i) & 1u) ? -(int)mag[i] : (int)mag[i];
+			if (bias && v)
+				v += v < 0 ? -bias : bias;
+			val[i] = v;
+		}
+		store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], j, lane, sq_lds[threadIdx.x >> 6], val);
+		return;
+	}
 	int *dst = lin + (long)plane * g.lin_stride + base + first;
 	if (nvalid == TILE) {
 #pragma unroll
@@ -1414,9 +1434,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // is valid and every kernel writing those images' planes has been enqueued on ctx->stream (or
 // ordered before it): the caller can queue its own follow-up work for that part of the batch
 // there while the rest of the batch is still being decoded.
-int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
+int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8_t *streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
-	int (*done)(void *user, int first, int count), void *user)
+	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user)
 {
 	if (!ctx || !lin || !streams || !dev_lens || !host_info || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 ||
 		(stream_stride & 7) || stream_stride < 64)
@@ -1435,6 +1455,17 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	g.total = (long)W * H;
 	g.lin_stride = g.total;
 	g.levels_max = levels_max < 0 || levels_max > g.levels ? g.levels : levels_max;
+	g.pyr = nullptr;
+	g.sq_levels = 0;
+	{
+		dwtx_geom gg;
+		dwtx_geometry(&gg, W, H);
+		for (int l = 0; l <= g.levels; ++l)
+			g.side[l] = l < g.levels ? gg.lengths[l + 1] : 0;
+	}
+	// the levels that are full power-of-two squares can go straight into the pyramid (k_apply_all)
+	const unsigned sq_all = pyr && !((uintptr_t)pyr & 15) && !getenv("DWTX_NO_SQUARE_TILES") ? dwtx_square_levels(W, H) : 0u;
+	unsigned part_mask[2] = { 0u, 0u };
 	int NT = 0;
 	for (int l = 0; l < g.levels; ++l) {
 		g.tile_first[l] = NT;
@@ -1635,7 +1666,16 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 			hipLaunchKernelGGL(k_rank, dim3(g.levels, cnt * C), dim3(1024), 0, st, g, h, p);
 			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT * COUNT_LANES, 256), cnt * C), dim3(256), 0, st, g, h, p);
 		}
-		hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), cnt * C), dim3(256), 0, st, g, h,
+		// Whole-resolution images only (decode.c:251-254: a stream that ends early gives a smaller picture, whose
+		// pyramid has another pitch): then reconstruction() of the square levels happens inside k_apply_all.
+		bool whole = sq_all != 0;
+		for (int i = i0; i < i0 + cnt; ++i)
+			whole = whole && !host_info[i].status && host_info[i].level == g.levels - 1;
+		UnpackGeom ga = g;
+		ga.sq_levels = whole ? sq_all : 0u;
+		ga.pyr = whole ? pyr + (size_t)i0 * C * g.lin_stride : nullptr;
+		part_mask[i0 ? 1 : 0] = ga.sq_levels;
+		hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), cnt * C), dim3(256), 0, st, ga, h,
 			streams + (size_t)i0 * stream_stride, (long)stream_stride, lin + (size_t)i0 * C * g.lin_stride);
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
@@ -1644,7 +1684,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
 		if ((rc = pre(s, 0, n)) || (rc = walk(s, 0, n)) || (rc = post(s, 0, n)))
 			return rc;
-		return done ? done(user, 0, n) : DWTX_OK;
+		return done ? done(user, 0, n, part_mask[0]) : DWTX_OK;
 	}
 	// The token walk is one wave per image and leaves the chip idle: run the two halves of the batch
 	// on two streams, the second one half a pipeline behind, so that each half's walk overlaps the
@@ -1656,17 +1696,17 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, s
 	DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
 	if ((rc = walk(s, 0, na)) || (rc = pre(ctx->aux, na, n - na)) || (rc = walk(ctx->aux, na, n - na)))
 		return rc;
-	if ((rc = post(s, 0, na)) || (done && (rc = done(user, 0, na))))   // the first half's follow-up overlaps the second half's walk
+	if ((rc = post(s, 0, na)) || (done && (rc = done(user, 0, na, part_mask[0]))))   // the first half's follow-up overlaps the second half's walk
 		return rc;
 	if ((rc = post(ctx->aux, na, n - na)))
 		return rc;
 	DWTX_HIP(hipEventRecord(ctx->ev[1], ctx->aux));
 	DWTX_HIP(hipStreamWaitEvent(s, ctx->ev[1], 0));
-	return done ? done(user, na, n - na) : DWTX_OK;
+	return done ? done(user, na, n - na, part_mask[1]) : DWTX_OK;
 }
 
 extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info)
 {
-	return dwtx_decode_planes_ex(ctx, lin, streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info, nullptr, nullptr);
+	return dwtx_decode_planes_ex(ctx, lin, nullptr, streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info, nullptr, nullptr);
 }

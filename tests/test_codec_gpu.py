@@ -375,3 +375,41 @@ def test_config_c_1024_frames_of_1080p_rgb_in_one_call(ctx):
     assert ok
     del out, tight, pix
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 1), (128, 128, 3), (256, 256, 1), (512, 512, 3)])
+def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, monkeypatch):
+    """Full power-of-two square levels skip the linearised copy: the coder reads their tiles from the pyramid's
+    32x32 Hilbert squares and the decoder writes them there (bias of never-decoded planes included,
+    decode.c:51-58).  Same bytes and pictures as the oracle, whole and cut at many lengths (cuts inside the
+    finest level keep the full resolution, i.e. the fused path with a bias), alone and in a mixed batch; and the
+    same bytes as the path that linearises everything."""
+    H, W, Cn = shape
+    for kind in (0, 1):
+        pix = orc.synth(W, H, Cn, 31 + kind, kind)
+        full, _ = ctx.encode(pix)
+        assert full == orc.encode(pix)[0]
+        assert (ctx.decode(full) == pix).all()
+        cuts = sorted({len(full) * k // 23 for k in range(1, 23)} | {len(full) - 1, len(full) - 9})
+        for cap in cuts:
+            want = orc.decode(full[:cap])
+            got = ctx.decode(full[:cap])
+            assert (want is None and got is None) or (got.shape == want.shape and (got == want).all()), cap
+    # a batch whose members end at different places (both decoder halves, per-image finishing)
+    n = 6
+    pixs = np.stack([orc.synth(W, H, Cn, 90 + i, i & 1) for i in range(n)])
+    streams, _ = ctx.encode(pixs)
+    for i in range(n):
+        assert streams[i] == orc.encode(pixs[i])[0]
+    streams[1] = streams[1][: len(streams[1]) * 9 // 10]
+    streams[4] = streams[4][: len(streams[4]) // 3]
+    outs = ctx.decode(streams)
+    for i in range(n):
+        want = orc.decode(streams[i])
+        assert outs[i].shape == want.shape and (outs[i] == want).all(), i
+    monkeypatch.setenv("DWTX_NO_SQUARE_TILES", "1")
+    plain, _ = ctx.encode(pixs)
+    assert plain == [orc.encode(pixs[i])[0] for i in range(n)]
+    outs2 = ctx.decode(streams)
+    for i in range(n):
+        assert (outs2[i] == outs[i]).all()
