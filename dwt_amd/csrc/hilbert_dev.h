@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int BLK_LOG2 = 5;                 // 32x32 squares
-constexpr int SQ_PITCH = 33;                // LDS pitch of a staged square (conflict-free rows and columns)
+constexpr int SQ_PITCH = 36;                // LDS pitch of a staged square: rows stay 16-byte aligned, eight consecutive rows hit different banks
 
 struct HilbertLow {
 	unsigned short xy[1 << (2 * BLK_LOG2)];
@@ -99,19 +99,22 @@ __device__ __forceinline__ void sq_wave_sync()
 }
 
 // LDS position (row * SQ_PITCH + column inside the square) of the 16 curve points 16*lane .. 16*lane+15 of the
-// square `m` describes
+// square `m` describes.  Two table entries (x | y << 8 each) share a register: one XOR flips both, a byte
+// permute swaps x and y of both.
 __device__ __forceinline__ void square_positions16(const SquareMap &m, int lane, unsigned (&pos)[16])
 {
-	const unsigned a = m.mx & 31u, b = m.my & 31u;
+	const unsigned ab = ((m.mx & 31u) | (m.my & 31u) << 8) * 0x00010001u;
 	const uint4 e0 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane);
 	const uint4 e1 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane + 8);
 	const unsigned e[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
 #pragma unroll
-	for (int k = 0; k < 16; ++k) {
-		const unsigned w = (e[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-		const unsigned xl = w & 31u, yl = (w >> 8) & 31u;
-		const unsigned x5 = (m.sw ? yl : xl) ^ a, y5 = (m.sw ? xl : yl) ^ b;
-		pos[k] = y5 * SQ_PITCH + x5;
+	for (int k = 0; k < 8; ++k) {
+		unsigned w = e[k];
+		if (m.sw)   // uniform
+			w = __builtin_amdgcn_perm(w, w, 0x02030001u);   // bytes (x0 y0 x1 y1) -> (y0 x0 y1 x1)
+		w ^= ab;
+		pos[2 * k] = ((w >> 8) & 255u) * SQ_PITCH + (w & 255u);
+		pos[2 * k + 1] = (w >> 24) * SQ_PITCH + ((w >> 16) & 255u);
 	}
 }
 
@@ -126,11 +129,7 @@ __device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr,
 	for (int it = 0; it < 4; ++it) {
 		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
 		const int4 v = *reinterpret_cast<const int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4);
-		unsigned *t = lds + row * SQ_PITCH + c4;
-		t[0] = (unsigned)v.x;
-		t[1] = (unsigned)v.y;
-		t[2] = (unsigned)v.z;
-		t[3] = (unsigned)v.w;
+		*reinterpret_cast<int4 *>(lds + row * SQ_PITCH + c4) = v;
 	}
 	unsigned pos[16];
 	square_positions16(m, lane, pos);
@@ -156,8 +155,7 @@ __device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int 
 #pragma unroll
 	for (int it = 0; it < 4; ++it) {
 		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-		const unsigned *t = lds + row * SQ_PITCH + c4;
-		*reinterpret_cast<int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4) = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+		*reinterpret_cast<int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4) = *reinterpret_cast<const int4 *>(lds + row * SQ_PITCH + c4);
 	}
 	sq_wave_sync();
 }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
-	__shared__ unsigned sq_lds[4][32 * SQ_PITCH];
+	__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][32 * SQ_PITCH];
 	int val[16];
 	load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, sq_lds[threadIdx.x >> 6], val);
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_stage_zero(Work w)
 constexpr int TABP = 18;             // dwords per lane in the class table (9 pairs: ds_read_b64 conflict-free over 32 lanes)
 constexpr int ROWW = 34;             // words per staging row of one plane (31 + 1024 bits + slack)
 
-struct CodeLds {
+struct alignas(16) CodeLds {
 	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1] | (t-1) << 12,  first slot of plane t-1 + Z[t] - Z[t-1] };
 	                                 // more: [lane][t-1] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
 	unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 10 | plane << 12
