@@ -727,6 +727,10 @@ __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 // the tokens of every chunk (piece) the walker did not set itself -> symbits
 __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
 {
+	constexpr int HB_WORDS = 16;   // 256 symbols
+	__shared__ unsigned hb[256 * (HB_WORDS + 1)];
+	for (int i = 0; i <= HB_WORDS; ++i)
+		hb[threadIdx.x * (HB_WORDS + 1) + i] = 0u;   // each thread only ever touches its own row
 	const int img = blockIdx.y;
 	const int nh = w.nhops[img];
 	const long nchunks = w.nch[img];
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 	const long n = w.NCH + 1;
 	ChunkWin c;
 	bool loaded = false;
+	unsigned *mybuf = hb + threadIdx.x * (HB_WORDS + 1);
 	// the tokens record h accounts for in this thread's chunk
 	auto piece = [&](int h) {
 		const int hs = w.hop_seg[(long)img * w.MAX_HOPS + h];
@@ -771,37 +776,66 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 			off = (int)(entry & 0xff);
 			o = (int)(entry >> 8);
 		}
-		// Symbol positions only grow: gather the bits of one bitmap word before touching memory.  The
-		// words strictly inside this piece's symbol range belong to it alone (neighbouring pieces and the
-		// walker's own tokens can only share its first and last word), so only those two need atomics.
+		// The piece's ones go to a window of HB_WORDS bitmap words that the thread keeps in LDS (a chunk of dense
+		// tokens spans about half of it; ones beyond the window — long zero runs — go to memory directly).  The
+		// words strictly inside the piece's symbol range belong to it alone (neighbouring pieces and the walker's
+		// own tokens can only share its first and last word): plain stores, only those two need atomics.
 		// A piece stays inside its segment (< 2^28 symbols): positions are 32-bit offsets from its first word.
 		unsigned *wp = sym + (pos >> 4);
-		unsigned rp = (unsigned)(pos & 15);
-		unsigned cur = 0xffffffffu, acc = 0;
-		bool first = true;
-		chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
-			if (!left)
-				return false;
-			rp += run;
-			const unsigned wi = rp >> 4;
-			if (wi != cur) {
-				if (acc) {
-					if (first)
-						atomicOr(wp + cur, acc);
-					else
-						wp[cur] = acc;
-					first = false;
-				}
-				cur = wi;
-				acc = 0;
+		const unsigned rp0 = (unsigned)(pos & 15);
+		unsigned rp = rp0;
+		bool beyond = false;   // some one fell outside the LDS window
+		const int off0 = off, o0 = o;
+		if (left == 0xffffffffu) {
+			// a stitched chunk: every token of it counts — no per-token decisions at all
+			chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
+				rp += run;
+				const unsigned wi = rp >> 4;
+				beyond = beyond || wi >= (unsigned)HB_WORDS;
+				atomicOr(&mybuf[wi < (unsigned)HB_WORDS ? wi : (unsigned)HB_WORDS], (1u | (neg << 1)) << ((rp & 15u) * 2u));
+				++rp;
+				return true;
+			});
+		} else {
+			chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
+				if (!left)
+					return false;
+				rp += run;
+				const unsigned wi = rp >> 4;
+				beyond = beyond || wi >= (unsigned)HB_WORDS;
+				atomicOr(&mybuf[wi < (unsigned)HB_WORDS ? wi : (unsigned)HB_WORDS], (1u | (neg << 1)) << ((rp & 15u) * 2u));
+				++rp;
+				--left;
+				return true;
+			});
+		}
+		if (beyond) {   // rare (long zero runs): the ones beyond the window go to memory one by one
+			unsigned rq = rp0, lq = w.hop_ntok[(long)img * w.MAX_HOPS + h];
+			int off1 = off0, o1 = o0;
+			chunk_walk(c, off1, o1, [&](unsigned run, unsigned neg) {
+				if (!lq)
+					return false;
+				rq += run;
+				if ((rq >> 4) >= (unsigned)HB_WORDS)
+					atomicOr(wp + (rq >> 4), (1u | (neg << 1)) << ((rq & 15u) * 2u));
+				++rq;
+				--lq;
+				return true;
+			});
+			mybuf[HB_WORDS] = 0u;
+		}
+		const unsigned lastw = rp > rp0 ? (rp - 1) >> 4 : 0u;
+#pragma unroll
+		for (int i = 0; i < HB_WORDS; ++i) {
+			const unsigned v = mybuf[i];
+			if (v) {
+				if (i == 0 || (unsigned)i >= lastw)
+					atomicOr(wp + i, v);
+				else
+					wp[i] = v;
+				mybuf[i] = 0u;
 			}
-			acc |= (1u | (neg << 1)) << ((rp & 15u) * 2u);
-			++rp;
-			--left;
-			return true;
-		});
-		if (acc)
-			atomicOr(wp + cur, acc);
+		}
 	};
 	const bool mine = chunk < w.nch[img] && chunk >= 1;
 	// Most workgroups lie inside one long hop: its record is then the same for every thread and is
