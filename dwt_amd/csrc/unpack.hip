@@ -1272,14 +1272,23 @@ __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 		const unsigned *sym = w.symbits + img * w.BW;
 		const unsigned long long a = 2 * (w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] + *rk);
 		const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
-		const unsigned long long first = a >> 5, last = (e - 1) >> 5;
-		for (unsigned long long wi = first + sub; wi <= last; wi += COUNT_LANES) {
-			unsigned m = sym[wi] & 0x55555555u;
-			if (wi == first)
-				m &= ~0u << (a & 31);
-			if (wi == last && (e & 31))
-				m &= (1u << (e & 31)) - 1u;
-			ones += (unsigned)__builtin_popcount(m);
+		const long first = (long)(a >> 5), last = (long)((e - 1) >> 5);
+		// the slice is at most 65 words: every lane takes four consecutive ones (a 16-byte load) per round
+		for (long w0 = (first & ~3l) + 4 * sub; w0 <= last; w0 += 4 * COUNT_LANES) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(sym + w0);
+			const unsigned x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const long wi = w0 + q;
+				unsigned m = x[q] & 0x55555555u;
+				if (wi < first || wi > last)
+					m = 0u;
+				if (wi == first)
+					m &= ~0u << (a & 31);
+				if (wi == last && (e & 31))
+					m &= (1u << (e & 31)) - 1u;
+				ones += (unsigned)__builtin_popcount(m);
+			}
 		}
 	}
 	for (int o = COUNT_LANES / 2; o; o >>= 1)
@@ -1515,7 +1524,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 #endif
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
-	w.BW = (long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 64;   // 2 bits per symbol
+	w.BW = ((long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 64 + 3) & ~3l;   // 2 bits per symbol; whole 16-byte groups per image
 	{
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
