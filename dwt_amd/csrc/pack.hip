@@ -51,7 +51,6 @@
 namespace {
 
 constexpr int TILE = 1024;
-constexpr int ROWS = TILE / 64;
 constexpr int NCUM = 32;              // cum[0..31]
 constexpr int MAX_PLANES = 16;        // 8-bit sources stay far below (checked in k_plan)
 constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
@@ -62,8 +61,7 @@ constexpr int GROUP = 64;             // chunks per group
 // A token is 16 bits: zero run (0xfff: the run is in tok_big[t]), sign of the one that ends it, and what
 // kind of slot it is.  Ones carry a sign; a segment's break slot (phantom terminator, rle.h:79-89) and the
 // final flush (encode.c:221) do not; a void slot emits nothing (but a break still has its refinement block).
-constexpr unsigned T_RUN = 0x0fffu, T_ESC = 0x0fffu, T_SIGN = 1u << 12, T_BREAK = 1u << 13, T_VOID = 1u << 14,
-	T_NOSIGN = 1u << 15;
+constexpr unsigned T_RUN = 0x0fffu, T_ESC = 0x0fffu, T_BREAK = 1u << 13, T_VOID = 1u << 14, T_NOSIGN = 1u << 15;   // sign: bit 12
 
 struct PackGeom {
 	int levels, C, W, H;
@@ -112,6 +110,7 @@ struct Work {
 	int *segidx;                // [n][3][16][MAX_PLANES] -> k+1 of the segment coding (channel, level, plane)
 	// per entry
 	unsigned short *ent_ones, *ent_zeros, *ent_refs, *ent_tz;   // [n][ES]
+	unsigned short *ent_seg;    // [n][ES] the entry's segment (k_entries_count looks it up once)
 	unsigned *ent_tokbase;      // [n][ES+1]
 	unsigned *ent_refscum;      // [n][ES+1]
 	// per token
@@ -515,6 +514,7 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_count(PackGeom g, Work w)
 		const int cnt = left < TILE ? (int)left : TILE;
 		const unsigned short *cum = w.cum + ((long)(img * g.C + c) * w.NT + g.tile_first[l] + j) * NCUM;
 		const int z = cum[p], upto = cum[p + 1];
+		w.ent_seg[img * w.ES + e] = (unsigned short)k;
 		w.ent_zeros[img * w.ES + e] = (unsigned short)z;
 		w.ent_ones[img * w.ES + e] = (unsigned short)(upto - z);
 		w.ent_refs[img * w.ES + e] = (unsigned short)(cnt - upto);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_stage_zero(Work w)
 	if (!refs)
 		return;
 	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int k = seg_of_entry(eb, I.K, e);
+	const int k = w.ent_seg[img * w.ES + e];
 	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
 	const unsigned long long bit0 = (w.seg_stage[(long)img * (MAX_SEGS + 1) + k] << 5) + (refscum[e] - refscum[eb[k]]);
 	unsigned *st = w.stage + img * w.SW;
@@ -955,7 +955,7 @@ __device__ __forceinline__ RunMap carry_map_of(const Work &w, const ImgInfo &I, 
 		has_one = w.ent_ones[img * w.ES + e] != 0;
 		t.keep = has_one ? 0u : 1u;
 		t.add = w.ent_tz[img * w.ES + e];
-		const int k = seg_of_entry(eb, I.K, e);
+		const int k = w.ent_seg[img * w.ES + e];
 		seg_end = e == eb[k + 1] - 1;
 		refs = seg_end && w.seg_refs[(long)img * MAX_SEGS + k] != 0;
 	}
@@ -1726,16 +1726,16 @@ __global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, lon
 	const long first = ((long)w.info[img].hdr_bits + 31) >> 5;
 	long last = (long)((w.stream_bits[img] + 31) >> 5) + 4;
 	last = last < out_words ? last : out_words;
-	const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-	if (i >= last || i + 4 <= first)
-		return;
-	unsigned *dst = out + img * out_words + i;
-	if (i >= first && i + 4 <= last) {
-		*reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
-	} else {
-		for (int k = 0; k < 4; ++k)
-			if (i + k >= first && i + k < last)
-				dst[k] = 0u;
+	unsigned *base = out + img * out_words;
+	for (long i = ((first & ~3l) >> 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < last; i += (long)gridDim.x * blockDim.x) {
+		unsigned *dst = base + i * 4;
+		if (i * 4 >= first && i * 4 + 4 <= last) {
+			*reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+		} else {
+			for (int k = 0; k < 4; ++k)
+				if (i * 4 + k >= first && i * 4 + k < last)
+					dst[k] = 0u;
+		}
 	}
 }
 
@@ -1890,6 +1890,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		const size_t o_ze = take(sizeof(short) * (size_t)n * w.ES);
 		const size_t o_re = take(sizeof(short) * (size_t)n * w.ES);
 		const size_t o_tz = take(sizeof(short) * (size_t)n * w.ES);
+		const size_t o_sg = take(sizeof(short) * (size_t)n * w.ES);
 		const size_t o_tb = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_rc = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_ca = take(sizeof(RunMap) * (size_t)n * w.NCB);
@@ -1902,6 +1903,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.ent_zeros = (unsigned short *)(ent + o_ze);
 		w.ent_refs = (unsigned short *)(ent + o_re);
 		w.ent_tz = (unsigned short *)(ent + o_tz);
+		w.ent_seg = (unsigned short *)(ent + o_sg);
 		w.ent_tokbase = (unsigned *)(ent + o_tb);
 		w.ent_refscum = (unsigned *)(ent + o_rc);
 		w.carry_agg = (RunMap *)(ent + o_ca);
@@ -1961,7 +1963,10 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_chain_image, dim3(n), dim3(1024), 0, s, w);
 	hipLaunchKernelGGL(k_gorder_exact, dim3(512, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_bitscan, dim3(n), dim3(1024), 0, s, w, capacity);
-	hipLaunchKernelGGL(k_clear_stream, dim3((unsigned)((out_words / 4 + 256) / 256), n), dim3(256), 0, s, w, outw, out_words);
+	{
+		const long cb = (out_words / 4 + 256) / 256;
+		hipLaunchKernelGGL(k_clear_stream, dim3((unsigned)(cb < 1024 ? cb : 1024), n), dim3(256), 0, s, w, outw, out_words);
+	}
 	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / CHUNK + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
 	hipLaunchKernelGGL(k_refcopy, dim3(1024, n), dim3(256), 0, s, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();

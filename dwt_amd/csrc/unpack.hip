@@ -44,7 +44,6 @@
 namespace {
 
 constexpr int TILE = 1024;
-constexpr int ROWS = TILE / 64;
 constexpr int MAX_PLANES = 16;
 constexpr int MAX_SEGS = 3 * 16 * MAX_PLANES;
 constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bits
