@@ -1306,6 +1306,45 @@ __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 // 32-bit window of the symbol bitmap and one of the stream's refinement block and hands the bits out to its
 // 16 coefficients in order.  The tile is written once, already in two's complement (decode.c:102-117 process()).
 
+// Handing bits out to the coefficients of a lane, four coefficients per table look-up.
+// DEP_SYM[m][s]: m = 4-bit mask of coefficients that take a pass-1 symbol, s = the next four symbols (two bits
+// each: one flag, sign): the symbols go, in order, to the set bits of m.  Entry = ones | (signs of those ones) << 4.
+// DEP_REF[m][b]: the same for plain bits (refinement).
+struct DepositTables {
+	unsigned char sym[16 * 256];
+	unsigned char ref[16 * 16];
+};
+
+constexpr DepositTables make_deposit_tables()
+{
+	DepositTables t{};
+	for (unsigned m = 0; m < 16; ++m) {
+		for (unsigned s = 0; s < 256; ++s) {
+			unsigned ones = 0, signs = 0, k = 0;
+			for (unsigned j = 0; j < 4; ++j)
+				if ((m >> j) & 1u) {
+					const unsigned one = (s >> (2 * k)) & 1u, sg = (s >> (2 * k + 1)) & 1u;
+					ones |= one << j;
+					signs |= (one & sg) << j;
+					++k;
+				}
+			t.sym[m * 256 + s] = (unsigned char)(ones | signs << 4);
+		}
+		for (unsigned b = 0; b < 16; ++b) {
+			unsigned out = 0, k = 0;
+			for (unsigned j = 0; j < 4; ++j)
+				if ((m >> j) & 1u) {
+					out |= ((b >> k) & 1u) << j;
+					++k;
+				}
+			t.ref[m * 16 + b] = (unsigned char)out;
+		}
+	}
+	return t;
+}
+
+__device__ const DepositTables DEPOSIT = make_deposit_tables();
+
 struct __attribute__((packed, aligned(4))) Int4S {
 	int x, y, z, w;
 };
@@ -1323,6 +1362,13 @@ __device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
 
 __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
 {
+	// the deposit tables in LDS (4352 bytes, 17 per thread), before any wave leaves
+	__shared__ __attribute__((aligned(16))) unsigned char dep[sizeof(DepositTables)];
+	static_assert(sizeof(DepositTables) == 17 * 256, "one 16-byte piece and one byte per thread");
+	*reinterpret_cast<uint4 *>(dep + 16 * threadIdx.x) = *reinterpret_cast<const uint4 *>(DEPOSIT.sym + 16 * threadIdx.x);
+	dep[4096 + threadIdx.x] = DEPOSIT.ref[threadIdx.x];
+	__syncthreads();
+	const unsigned char *dsym = dep, *dref = dep + 4096;
 	const int lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int plane = blockIdx.y;
@@ -1350,9 +1396,8 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	for (int i = 0; i < 16; ++i)
 		mag[i] = 0;
 	unsigned neg = 0;                       // bit i: coefficient i of this lane is negative
-	unsigned ins = (1u << nv) - 1u;         // bit i: coefficient i is still insignificant (nv = 16 at most)
-	if (nv == 16)
-		ins = 0xffffu;
+	const unsigned valid16 = nv >= 16 ? 0xffffu : (1u << nv) - 1u;
+	unsigned ins = valid16;                 // bit i: coefficient i is still insignificant
 	bool anysig = false;                    // uniform: some coefficient of the tile is significant
 	for (int p = I.planes[c] - 1; p >= 0; --p) {
 		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
@@ -1390,18 +1435,25 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			const unsigned x0 = stream[wi], x1 = sh + avail > 32u && wi + 1 < stream_words ? stream[wi + 1] : 0u;
 			r16 = __builtin_amdgcn_alignbit(x1, x0, sh) & ((1u << avail) - 1u);   // avail <= 16
 		}
+		// four coefficients per look-up: symbols to the insignificant ones, refinement bits to the others, in order
+		const unsigned sig = valid16 & ~ins;
+		unsigned ones16 = 0, sgn16 = 0, ref16 = 0;
 #pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const bool isz = (ins >> i) & 1u;
-			const unsigned sb = s32 & 3u;
-			const unsigned one = isz ? sb & 1u : 0u;
-			const unsigned bit = isz ? one : r16 & 1u;
-			mag[i] |= bit << p;
-			neg |= (one & (sb >> 1)) << i;      // the sign follows a pass-1 one (decode.c:80-85)
-			ins ^= one << i;
-			s32 = isz ? s32 >> 2 : s32;
-			r16 = isz ? r16 : r16 >> 1;
+		for (int n4 = 0; n4 < 4; ++n4) {
+			const unsigned mi = (ins >> (4 * n4)) & 15u, ms = (sig >> (4 * n4)) & 15u;
+			const unsigned es = dsym[mi * 256u + (s32 & 255u)], er = dref[ms * 16u + (r16 & 15u)];
+			ones16 |= (es & 15u) << (4 * n4);
+			sgn16 |= (es >> 4) << (4 * n4);
+			ref16 |= er << (4 * n4);
+			s32 >>= 2 * __builtin_popcount(mi);
+			r16 >>= __builtin_popcount(ms);
 		}
+		const unsigned bits16 = ones16 | ref16;
+		neg |= sgn16;                            // the sign follows a pass-1 one (decode.c:80-85)
+		ins &= ~ones16;
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			mag[i] |= ((bits16 >> i) & 1u) << p;
 	}
 	if ((g.sq_levels >> l) & 1u) {
 		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
