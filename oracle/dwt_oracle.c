@@ -506,12 +506,27 @@ int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 	if (W < 8 || H < 8 || W > 65536 || H > 65536 || (C != 1 && C != 3))
 		return 1;                                   /* encode.c:140-146 */
 	orc_geom g;
-	int levels = orc_geometry(&g, W, H, 8);
+	orc_geometry(&g, W, H, 8);
 	size_t total = (size_t)W * H;
 	int *img = pixels_to_coefs(pix, W, H, C);
 	int *lin = malloc(sizeof(int) * total * C);
 	orc_linearize(lin, img, &g, C);               /* encode.c:160 */
 	free(img);
+	int rc = orc_encode_lin(lin, W, H, C, capacity, out, out_len, st);
+	free(lin);
+	return rc;
+}
+
+/* encode.c:163-230 on linearised coefficient planes lin[C][W*H] (what encode.c:160 leaves in `buffer`): the entropy
+ * stage alone, for tests that feed it coefficients no 8-bit picture produces (up to 16 bit planes) */
+int orc_encode_lin(const int *lin, int W, int H, int C, long capacity,
+	uint8_t **out, size_t *out_len, orc_stats *st)
+{
+	if (W < 8 || H < 8 || W > 65536 || H > 65536 || (C != 1 && C != 3))
+		return 1;
+	orc_geom g;
+	int levels = orc_geometry(&g, W, H, 8);
+	size_t total = (size_t)W * H;
 	uint32_t *sm = malloc(sizeof(uint32_t) * total * C);
 	int planes[3] = { 0, 0, 0 };
 	for (int c = 0; c < C; ++c)                   /* encode.c:163-165 */
@@ -574,7 +589,6 @@ int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 		for (int c = 0; c < 3; ++c)
 			st->planes[c] = planes[c];
 	}
-	free(lin);
 	free(sm);
 	*out = s.buf ? s.buf : malloc(1);
 	*out_len = s.len;

@@ -71,6 +71,9 @@ void orc_reconstruct(int *pyr, int *const *lin, const int *missing, const orc_ge
  * capacity <= 0 means unlimited.  *out is malloc'ed.  Returns 0, or 1 on bad size. */
 int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 	uint8_t **out, size_t *out_len, orc_stats *st);
+/* the entropy stage of orc_encode alone, on linearised coefficient planes lin[C][W*H] */
+int orc_encode_lin(const int *lin, int W, int H, int C, long capacity,
+	uint8_t **out, size_t *out_len, orc_stats *st);
 
 /* Whole-file decode.  pixels_max < 0 means "no PIXELS argument".  *pix is
  * malloc'ed (already clamped to 0..255 like pnm.h:108).  Returns 0 or 1. */

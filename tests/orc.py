@@ -30,6 +30,8 @@ def lib():
         L.orc_geometry.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, C.c_int]
         L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long,
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        L.orc_encode_lin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
         L.orc_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_stage_dump.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -67,6 +69,19 @@ def encode(pix, capacity=0):
     rc = lib().orc_encode(pix.ctypes.data, W, H, Cn, capacity, C.byref(out), C.byref(n), C.byref(st))
     if rc:
         raise ValueError("orc_encode rejected the image")
+    data = C.string_at(out, n.value)
+    _libc.free(out)
+    return data, st
+
+
+def encode_lin(lin, W, H, capacity=0):
+    """The entropy stage alone on linearised coefficient planes int32 [C, W*H] -> (.dwt bytes, Stats)."""
+    lin = np.ascontiguousarray(lin, dtype=np.int32)
+    Cn = lin.shape[0]
+    out, n, st = C.c_void_p(), C.c_size_t(), Stats()
+    rc = lib().orc_encode_lin(lin.ctypes.data, W, H, Cn, capacity, C.byref(out), C.byref(n), C.byref(st))
+    if rc:
+        raise ValueError("orc_encode_lin rejected the planes")
     data = C.string_at(out, n.value)
     _libc.free(out)
     return data, st

@@ -198,3 +198,18 @@ def test_statistics_lines_under_tiny_capacities_against_reference_binary(tmp_pat
             assert (tmp_path / "o.dwt").read_bytes() == data
             assert r.stderr.decode() == (f"{st.meta_bits} bits for meta data\n{st.root_bits} bits for root image\n"
                                          f"{st.total_bits} bits ({st.kib} KiB) encoded\n")
+
+
+def test_entropy_stage_entry_equals_the_whole_encoder():
+    """orc_encode_lin (the coder on given linearised planes, used by the GPU tests for coefficient ranges no 8-bit
+    picture produces) is the same code path orc_encode runs after its transform: same bytes on pictures, and
+    planes with 15 bit planes decode back."""
+    for W, H, Cn in ((131, 77, 3), (64, 64, 1), (300, 17, 1)):
+        pix = orc.synth(W, H, Cn, 3, 0)
+        _, lin, _ = orc.stage_dump(pix)
+        assert orc.encode_lin(lin, W, H)[0] == orc.encode(pix)[0]
+    rng = np.random.default_rng(1)
+    lin = (rng.integers(-30000, 30000, (1, 64 * 64)) * (rng.random((1, 64 * 64)) < 0.3)).astype(np.int32)
+    data, st = orc.encode_lin(lin, 64, 64)
+    assert list(st.planes)[:1] == [15]
+    assert (orc.decode_stage(data, 64, 64, 1)[0] == lin).all()

@@ -81,3 +81,40 @@ def test_1080p_rgb_and_4096_gray(ctx):
         streams, _ = ctx.encode_planes(torch.from_numpy(lin).cuda(), rec["W"], rec["H"], rec["C"])
         assert len(streams[0]) == rec["dwt_len"]
         assert hashlib.sha256(streams[0]).hexdigest() == rec["dwt_sha256"]
+
+
+def _synthetic_planes(rng, W, H, Cn, bits, density):
+    """Linearised coefficient planes no 8-bit picture produces: magnitudes up to `bits` bits, a share `density`
+    of non-zero coefficients (sparse planes -> zero runs across tiles, segments and channels)."""
+    n = W * H
+    lin = np.zeros((Cn, n), dtype=np.int64)
+    for c in range(Cn):
+        nz = rng.random(n) < density
+        mag = (rng.integers(1, 1 << bits, n) >> rng.integers(0, bits, n)).clip(1)   # all bit lengths occur
+        lin[c] = np.where(nz, mag * rng.choice([-1, 1], n), 0)
+    return lin.astype(np.int32)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 1, 16, 0.5), (200, 120, 3, 16, 0.02), (256, 256, 1, 13, 0.9), (333, 111, 3, 10, 0.3),
+                                  (512, 384, 1, 16, 0.0005), (96, 96, 3, 9, 1.0), (1024, 512, 1, 12, 0.001)])
+def test_entropy_stage_on_synthetic_coefficient_planes(ctx, case):
+    """dwtx_encode_planes / dwtx_decode_planes on coefficient planes with up to 16 bit planes (the 64-bit count
+    registers of k_code), very sparse ones (runs of hundreds of thousands: escaped tokens, high VLI orders, codes
+    longer than 32 bits) and dense ones: bytes equal the oracle's entropy stage, both decode back."""
+    import torch
+
+    W, H, Cn, bits, density = case
+    rng = np.random.default_rng(W * 7 + H + bits)
+    lin = _synthetic_planes(rng, W, H, Cn, bits, density)
+    want, st = orc.encode_lin(lin, W, H)
+    streams, infos = ctx.encode_planes(torch.from_numpy(lin).cuda(), W, H, Cn)
+    assert list(infos[0].planes)[:Cn] == list(st.planes)[:Cn]
+    assert streams[0] == want
+    got = orc.decode_stage(want, W, H, Cn)
+    assert got is not None and (got[0] == lin).all()
+    back, dinfos = ctx.decode_planes([want], W, H, Cn)
+    assert dinfos[0].status == 0 and not dinfos[0].truncated
+    assert (back.cpu().numpy() == lin).all()
+    for cap in (len(want) // 3, len(want) - 5):
+        cut, _ = ctx.encode_planes(torch.from_numpy(lin).cuda(), W, H, Cn, capacity=cap)
+        assert cut[0] == want[:cap]
