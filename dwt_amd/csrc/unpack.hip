@@ -727,7 +727,10 @@ __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
 {
 	constexpr int HB_WORDS = 16;   // 256 symbols
+	constexpr int HB_WIN = 2048;   // the workgroup's window: 32768 symbols
 	__shared__ unsigned hb[256 * (HB_WORDS + 1)];
+	__shared__ unsigned win[HB_WIN];
+	__shared__ unsigned win_last;
 	for (int i = 0; i <= HB_WORDS; ++i)
 		hb[threadIdx.x * (HB_WORDS + 1) + i] = 0u;   // each thread only ever touches its own row
 	const int img = blockIdx.y;
@@ -840,8 +843,65 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 	// Most workgroups lie inside one long hop: its record is then the same for every thread and is
 	// fetched through the scalar unit; only the chunk's own table rows are per-thread loads.
 	if (lo < nh && hf[lo] <= first_chunk && hl[lo] >= first_chunk + blockDim.x - 1 && (lo + 1 >= nh || hf[lo + 1] > first_chunk + blockDim.x - 1)) {
-		if (mine)
-			piece(lo);
+		const int hs = w.hop_seg[(long)img * w.MAX_HOPS + lo];
+		const int k = hs & 0xffff, vs = img * FAM + (hs >> 16);
+		const bool stitched = w.hop_entry[(long)img * w.MAX_HOPS + lo] == 0xffffffffu && first_chunk >= 1;
+		if (!stitched) {
+			if (mine)
+				piece(lo);
+			continue;
+		}
+		if ((w.seg_desc[(long)img * MAX_SEGS + k] >> 8) == 0)
+			continue;   // plane -1 (flat image): symbols carry no bits
+		// All 256 chunks lie inside one stitched run: their symbols are one gapless stretch of the segment.  The
+		// workgroup gathers the ones in an LDS window over that stretch (dense planes: ~100 symbols per chunk) and
+		// writes it out as whole words; everything strictly inside the stretch is this workgroup's alone, its
+		// first and last word are shared with the neighbours (atomics).  Ones beyond the window (long zero runs)
+		// go to memory directly.
+		const unsigned long long seg0 = w.seg_symbase[(long)img * MAX_SEGS + k] + w.hop_q0[(long)img * w.MAX_HOPS + lo] -
+			w.cs[vs * n + hf[lo]];
+		const unsigned long long base_w = (seg0 + w.cs[vs * n + first_chunk]) >> 4;   // uniform
+		for (int i = threadIdx.x; i < HB_WIN; i += 256)
+			win[i] = 0u;
+		if (threadIdx.x == 0)
+			win_last = 0u;
+		__syncthreads();
+		{
+			const ChunkWin cw = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+			const unsigned short in = w.exitX[vs * w.NCH + chunk - 1];
+			int off = in & 0xff, o = in >> 8;
+			unsigned roff = (unsigned)(seg0 + w.cs[vs * n + chunk] - (base_w << 4));   // symbols from the window's first one
+			const unsigned roff0 = roff;
+			unsigned *gp = sym + base_w;
+			chunk_walk(cw, off, o, [&](unsigned run, unsigned neg) {
+				roff += run;
+				const unsigned wi = roff >> 4;
+				const unsigned bits = (1u | (neg << 1)) << ((roff & 15u) * 2u);
+				if (wi < (unsigned)HB_WIN)
+					atomicOr(&win[wi], bits);
+				else
+					atomicOr(gp + wi, bits);
+				++roff;
+				return true;
+			});
+			if (roff > roff0) {
+				const unsigned lw = (roff - 1) >> 4;
+				atomicMax(&win_last, lw < (unsigned)HB_WIN - 1u ? lw : (unsigned)HB_WIN - 1u);
+			}
+		}
+		__syncthreads();
+		{
+			const unsigned lastw = win_last;
+			unsigned *gp = sym + base_w;
+			for (unsigned i = threadIdx.x; i <= lastw; i += 256) {
+				const unsigned v = win[i];
+				if (i > 0 && i < lastw)
+					gp[i] = v;
+				else if (v)
+					atomicOr(gp + i, v);
+			}
+		}
+		__syncthreads();   // the window is reused by the next virtual block
 		continue;
 	}
 	if (!mine)
