@@ -1458,62 +1458,122 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	unsigned neg = 0;                       // bit i: coefficient i of this lane is negative
 	const unsigned valid16 = nv >= 16 ? 0xffffu : (1u << nv) - 1u;
 	unsigned ins = valid16;                 // bit i: coefficient i is still insignificant
-	bool anysig = false;                    // uniform: some coefficient of the tile is significant
-	for (int p = I.planes[c] - 1; p >= 0; --p) {
-		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
-		if (!k1)
-			continue;
-		const int k = k1 - 1;
-		const unsigned tr = w.tile_rank[((long)plane * MAX_PLANES + p) * w.NT + tile];
-		// nothing to do while the tile is all zeros and this plane adds no ones to it (k_count's flag):
-		// on fine levels that is every plane above the noise floor
-		if (!(tr >> 31) && !anysig)
-			continue;
-		anysig = true;
-		const unsigned long long b2 = w.seg_b2[(long)img * MAX_SEGS + k];
-		const unsigned n2done = w.seg_n2done[(long)img * MAX_SEGS + k];
-		const unsigned ci = (unsigned)__builtin_popcount(ins);
-		const unsigned nb = wave_incl_add_u(ci) - ci;                 // insignificant coefficients in the lanes before
-		const unsigned r1 = (tr & 0x7fffffffu) + nb;                   // pass-1 symbol index of this lane's first insignificant one
-		const unsigned r2 = (unsigned)j * TILE + (unsigned)vb - r1;    // refinement index of its first significant one
-		// symbols: two bits each (one flag, sign); a segment's symbols start on a word boundary
-		unsigned s32 = 0;
-		if (ci) {
-			const unsigned *sp = sym + (w.seg_symbase[(long)img * MAX_SEGS + k] >> 4) + (r1 >> 4);
-			const unsigned sh = (r1 & 15u) * 2u;
-			const unsigned w0 = sp[0], w1 = sh ? sp[1] : 0u;
-			s32 = __builtin_amdgcn_alignbit(w1, w0, sh);
+
+	// What a plane needs from memory does not depend on the planes before it: the tile's slice of the symbol
+	// bitmap (its insignificant coefficients are consecutive symbols from the tile's rank: at most 65 words) and
+	// its slice of the segment's refinement block (at most 33 words).  Lane p fetches plane p's record, then the
+	// wave fetches the slices of up to AP_BATCH planes as coalesced rows and keeps them in LDS: all those round
+	// trips overlap instead of two dependent ones per plane.
+	constexpr int AP_BATCH = 8, SYMW = 66, REFW = 34;
+	__shared__ unsigned ap_sym[4][AP_BATCH][SYMW], ap_ref[4][AP_BATCH][REFW];
+	__shared__ unsigned ap_rank[4][MAX_PLANES], ap_n2[4][MAX_PLANES], ap_refbit[4][MAX_PLANES];
+	const int wv = threadIdx.x >> 6;
+	unsigned my_tr = 0, my_n2 = 0;
+	unsigned long long my_sb = 0, my_b2 = 0;
+	bool my_live = false;
+	if (lane < MAX_PLANES && lane < I.planes[c]) {
+		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + lane];
+		if (k1) {
+			my_live = true;
+			my_tr = w.tile_rank[((long)plane * MAX_PLANES + lane) * w.NT + tile];
+			my_sb = w.seg_symbase[(long)img * MAX_SEGS + k1 - 1];
+			my_b2 = w.seg_b2[(long)img * MAX_SEGS + k1 - 1];
+			my_n2 = w.seg_n2done[(long)img * MAX_SEGS + k1 - 1];
 		}
-		// refinement bits that the stream still holds for this lane (a truncated stream ends inside some block)
-		const unsigned cs = (unsigned)nv - ci;
-		const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
-		unsigned r16 = 0;
-		if (avail) {
-			const unsigned long long pb = b2 + r2;
-			const long wi = (long)(pb >> 5);
-			const unsigned sh = (unsigned)(pb & 31);
-			const unsigned x0 = stream[wi], x1 = sh + avail > 32u && wi + 1 < stream_words ? stream[wi + 1] : 0u;
-			r16 = __builtin_amdgcn_alignbit(x1, x0, sh) & ((1u << avail) - 1u);   // avail <= 16
-		}
-		// four coefficients per look-up: symbols to the insignificant ones, refinement bits to the others, in order
-		const unsigned sig = valid16 & ~ins;
-		unsigned ones16 = 0, sgn16 = 0, ref16 = 0;
+	}
+	// planes that do something: from the first one that turns a coefficient of this tile on (k_count's flag) downwards
+	const unsigned long long livem = ballot64(my_live), flagm = ballot64(my_live && (my_tr >> 31));
+	const int ptop = flagm ? 63 - __builtin_clzll(flagm) : -1;
+	unsigned long long todo = ptop >= 0 ? livem & ((2ull << ptop) - 1ull) : 0ull;
+	while (todo) {
+		// ---- fetch the slices of the next AP_BATCH planes (descending) ----
+		int pl[AP_BATCH];
+		unsigned long long t2 = todo;
 #pragma unroll
-		for (int n4 = 0; n4 < 4; ++n4) {
-			const unsigned mi = (ins >> (4 * n4)) & 15u, ms = (sig >> (4 * n4)) & 15u;
-			const unsigned es = dsym[mi * 256u + (s32 & 255u)], er = dref[ms * 16u + (r16 & 15u)];
-			ones16 |= (es & 15u) << (4 * n4);
-			sgn16 |= (es >> 4) << (4 * n4);
-			ref16 |= er << (4 * n4);
-			s32 >>= 2 * __builtin_popcount(mi);
-			r16 >>= __builtin_popcount(ms);
+		for (int q = 0; q < AP_BATCH; ++q) {
+			pl[q] = t2 ? 63 - __builtin_clzll(t2) : -1;
+			t2 &= pl[q] >= 0 ? ~(1ull << pl[q]) : ~0ull;
 		}
-		const unsigned bits16 = ones16 | ref16;
-		neg |= sgn16;                            // the sign follows a pass-1 one (decode.c:80-85)
-		ins &= ~ones16;
+		unsigned sv0[AP_BATCH], sv1[AP_BATCH], rv[AP_BATCH];
 #pragma unroll
-		for (int i = 0; i < 16; ++i)
-			mag[i] |= ((bits16 >> i) & 1u) << p;
+		for (int q = 0; q < AP_BATCH; ++q) {
+			sv0[q] = sv1[q] = rv[q] = 0u;
+			if (pl[q] < 0)
+				continue;   // uniform
+			const unsigned rank = (unsigned)__builtin_amdgcn_readlane((int)my_tr, pl[q]) & 0x7fffffffu;
+			const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_sb >> 32), pl[q]) << 32) |
+				(unsigned)__builtin_amdgcn_readlane((int)my_sb, pl[q]);
+			const unsigned long long b2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_b2 >> 32), pl[q]) << 32) |
+				(unsigned)__builtin_amdgcn_readlane((int)my_b2, pl[q]);
+			const unsigned n2 = (unsigned)__builtin_amdgcn_readlane((int)my_n2, pl[q]);
+			const unsigned *sp = sym + (sb >> 4) + (rank >> 4);                    // a segment's symbols start on a word boundary
+			sv0[q] = sp[lane];
+			if (lane < SYMW - 64)
+				sv1[q] = sp[64 + lane];
+			const unsigned r2t = (unsigned)j * TILE - rank;                        // refinement index of the tile's first significant coefficient
+			const unsigned long long rbit = b2 + r2t;
+			const long rw = (long)(rbit >> 5) + lane;
+			if (lane < REFW && r2t < n2 && rw < stream_words)
+				rv[q] = stream[rw];
+			if (lane == 0) {
+				ap_rank[wv][pl[q]] = rank;
+				ap_n2[wv][pl[q]] = n2;
+				ap_refbit[wv][pl[q]] = (unsigned)(rbit & 31);
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < AP_BATCH; ++q) {
+			if (pl[q] < 0)
+				continue;
+			ap_sym[wv][q][lane] = sv0[q];
+			if (lane < SYMW - 64)
+				ap_sym[wv][q][64 + lane] = sv1[q];
+			if (lane < REFW)
+				ap_ref[wv][q][lane] = rv[q];
+		}
+		sq_wave_sync();
+		// ---- the planes of the batch, in order ----
+		const int nbatch = __builtin_popcountll(todo) < AP_BATCH ? __builtin_popcountll(todo) : AP_BATCH;
+#pragma unroll 1
+		for (int q = 0; q < nbatch; ++q) {
+			const int p = 63 - __builtin_clzll(todo);
+			todo &= ~(1ull << p);
+			const unsigned rank = ap_rank[wv][p], n2done = ap_n2[wv][p];
+			const unsigned ci = (unsigned)__builtin_popcount(ins);
+			const unsigned nb = wave_incl_add_u(ci) - ci;                 // insignificant coefficients in the lanes before
+			// symbols: two bits each (one flag, sign), this lane's start `nb` symbols after the tile's
+			const unsigned srel = (rank & 15u) + nb;
+			const unsigned *sw = ap_sym[wv][q] + (srel >> 4);
+			unsigned s32 = __builtin_amdgcn_alignbit(sw[1], sw[0], (srel & 15u) * 2u);
+			// refinement bits that the stream still holds for this lane (a truncated stream ends inside some block)
+			const unsigned sb4 = (unsigned)vb - nb;                          // significant coefficients in the lanes before
+			const unsigned r2 = (unsigned)j * TILE - rank + sb4;             // refinement index of this lane's first significant one
+			const unsigned cs = (unsigned)nv - ci;
+			const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
+			const unsigned rrel = ap_refbit[wv][p] + sb4;
+			const unsigned *rwp = ap_ref[wv][q] + (rrel >> 5);
+			unsigned r16 = __builtin_amdgcn_alignbit(rwp[1], rwp[0], rrel & 31u) & ((1u << avail) - 1u);   // avail <= 16
+			// four coefficients per look-up: symbols to the insignificant ones, refinement bits to the others, in order
+			const unsigned sig = valid16 & ~ins;
+			unsigned ones16 = 0, sgn16 = 0, ref16 = 0;
+#pragma unroll
+			for (int n4 = 0; n4 < 4; ++n4) {
+				const unsigned mi = (ins >> (4 * n4)) & 15u, ms = (sig >> (4 * n4)) & 15u;
+				const unsigned es = dsym[mi * 256u + (s32 & 255u)], er = dref[ms * 16u + (r16 & 15u)];
+				ones16 |= (es & 15u) << (4 * n4);
+				sgn16 |= (es >> 4) << (4 * n4);
+				ref16 |= er << (4 * n4);
+				s32 >>= 2 * __builtin_popcount(mi);
+				r16 >>= __builtin_popcount(ms);
+			}
+			const unsigned bits16 = ones16 | ref16;
+			neg |= sgn16;                            // the sign follows a pass-1 one (decode.c:80-85)
+			ins &= ~ones16;
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				mag[i] |= ((bits16 >> i) & 1u) << p;
+		}
+		sq_wave_sync();   // the next batch overwrites the slices
 	}
 	if ((g.sq_levels >> l) & 1u) {
 		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
@@ -1635,7 +1695,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 #endif
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
-	w.BW = ((long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 64 + 3) & ~3l;   // 2 bits per symbol; whole 16-byte groups per image
+	w.BW = ((long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 128 + 3) & ~3l;   // 2 bits per symbol; whole 16-byte groups per image
 	{
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
