@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int BLK_LOG2 = 5;                 // 32x32 squares
-constexpr int SQ_PITCH = 36;                // LDS pitch of a staged square: rows stay 16-byte aligned, eight consecutive rows hit different banks
+constexpr int SQ_WORDS = 1024;              // LDS words of a staged square
 
 struct HilbertLow {
 	unsigned short xy[1 << (2 * BLK_LOG2)];
@@ -98,28 +98,48 @@ __device__ __forceinline__ void sq_wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS position (row * SQ_PITCH + column inside the square) of the 16 curve points 16*lane .. 16*lane+15 of the
-// square `m` describes.  Two table entries (x | y << 8 each) share a register: one XOR flips both, a byte
-// permute swaps x and y of both.
+// A staged square lives in LDS as 32 rows of 32 words, the 16-byte groups of a row XOR-swizzled with the row
+// (eight consecutive rows hit different banks): word (y, x) sits at (y << 5) | (x ^ ((y & 7) << 2)).  With
+// x = X ^ a, y = Y ^ b (X, Y the table's coordinates, swapped or not; a, b the low five bits of the square's
+// XOR masks) that position is  [(Y << 5) | (X ^ ((Y & 7) << 2))] ^ [(b << 5) | (a ^ ((b & 7) << 2))]:
+// a per-point constant XOR a per-square key.  SQUARE_POS holds the constants as byte offsets, for both swap states.
+struct SquarePos {
+	unsigned short off[2][1 << (2 * BLK_LOG2)];
+};
+
+constexpr SquarePos make_square_pos()
+{
+	SquarePos t{};
+	const HilbertLow h = make_hilbert_low();
+	for (unsigned i = 0; i < (1u << (2 * BLK_LOG2)); ++i) {
+		const unsigned xl = h.xy[i] & 255u, yl = h.xy[i] >> 8;
+		t.off[0][i] = (unsigned short)(((yl << 5) | (xl ^ ((yl & 7u) << 2))) << 2);
+		t.off[1][i] = (unsigned short)(((xl << 5) | (yl ^ ((xl & 7u) << 2))) << 2);
+	}
+	return t;
+}
+
+__device__ const SquarePos SQUARE_POS = make_square_pos();
+
+// byte offsets (inside the staged square) of the 16 curve points 16*lane .. 16*lane+15 of the square `m` describes
 __device__ __forceinline__ void square_positions16(const SquareMap &m, int lane, unsigned (&pos)[16])
 {
-	const unsigned ab = ((m.mx & 31u) | (m.my & 31u) << 8) * 0x00010001u;
-	const uint4 e0 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane);
-	const uint4 e1 = *reinterpret_cast<const uint4 *>(HILBERT_LOW.xy + 16 * lane + 8);
+	const unsigned a = m.mx & 31u, b = m.my & 31u;
+	const unsigned key = (((b << 5) | (a ^ ((b & 7u) << 2))) << 2) * 0x00010001u;
+	const unsigned short *tab = SQUARE_POS.off[m.sw ? 1 : 0];   // uniform
+	const uint4 e0 = *reinterpret_cast<const uint4 *>(tab + 16 * lane);
+	const uint4 e1 = *reinterpret_cast<const uint4 *>(tab + 16 * lane + 8);
 	const unsigned e[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		unsigned w = e[k];
-		if (m.sw)   // uniform
-			w = __builtin_amdgcn_perm(w, w, 0x02030001u);   // bytes (x0 y0 x1 y1) -> (y0 x0 y1 x1)
-		w ^= ab;
-		pos[2 * k] = ((w >> 8) & 255u) * SQ_PITCH + (w & 255u);
-		pos[2 * k + 1] = (w >> 24) * SQ_PITCH + ((w >> 16) & 255u);
+		const unsigned w = e[k] ^ key;
+		pos[2 * k] = w & 0xffffu;
+		pos[2 * k + 1] = w >> 16;
 	}
 }
 
 // Tile j of a full-square ring level (outer side n) of one plane: the wave reads the 32x32 square as whole
-// 128-byte rows, stages it in LDS (32*SQ_PITCH words) and every lane picks up its 16 consecutive curve points.
+// 128-byte rows, stages it in LDS (SQ_WORDS words, 16-byte aligned) and every lane picks up its 16 consecutive curve points.
 __device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr, int ppitch, int n, int j, int lane,
 	unsigned *lds, int (&val)[16])
 {
@@ -129,14 +149,15 @@ __device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr,
 	for (int it = 0; it < 4; ++it) {
 		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
 		const int4 v = *reinterpret_cast<const int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4);
-		*reinterpret_cast<int4 *>(lds + row * SQ_PITCH + c4) = v;
+		*reinterpret_cast<int4 *>(lds + ((row << 5) | (c4 ^ ((row & 7) << 2)))) = v;
 	}
 	unsigned pos[16];
 	square_positions16(m, lane, pos);
 	sq_wave_sync();
+	const char *base = reinterpret_cast<const char *>(lds);
 #pragma unroll
 	for (int k = 0; k < 16; ++k)
-		val[k] = (int)lds[pos[k]];
+		val[k] = *reinterpret_cast<const int *>(base + pos[k]);
 	sq_wave_sync();   // the caller may reuse the LDS words
 }
 
@@ -148,14 +169,16 @@ __device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int 
 	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
 	unsigned pos[16];
 	square_positions16(m, lane, pos);
+	char *base = reinterpret_cast<char *>(lds);
 #pragma unroll
 	for (int k = 0; k < 16; ++k)
-		lds[pos[k]] = (unsigned)val[k];
+		*reinterpret_cast<int *>(base + pos[k]) = val[k];
 	sq_wave_sync();
 #pragma unroll
 	for (int it = 0; it < 4; ++it) {
 		const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-		*reinterpret_cast<int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4) = *reinterpret_cast<const int4 *>(lds + row * SQ_PITCH + c4);
+		*reinterpret_cast<int4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c4) =
+			*reinterpret_cast<const int4 *>(lds + ((row << 5) | (c4 ^ ((row & 7) << 2))));
 	}
 	sq_wave_sync();
 }

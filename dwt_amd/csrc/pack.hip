@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
-	__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][32 * SQ_PITCH];
+	__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][SQ_WORDS];
 	int val[16];
 	load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, sq_lds[threadIdx.x >> 6], val);
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict_
 	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
 
 	// ---- the coefficients, once (the class table's LDS words stage a pyramid square meanwhile) ----
-	static_assert(sizeof(L.tab) >= sizeof(unsigned) * 32 * SQ_PITCH, "the class table doubles as the square's staging area");
+	static_assert(sizeof(L.tab) >= sizeof(unsigned) * SQ_WORDS, "the class table doubles as the square's staging area");
 	int val[16];
 	load_tile16(g, lin, plane, l, j, lane, nvalid, nv, L.tab, val);
 	// per-plane bookkeeping of this tile's entries (lanes 0..15 take a plane each): three dependent look-ups

@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	if ((g.sq_levels >> l) & 1u) {
 		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
 		// with the dead-zone bias of planes that were never decoded (decode.c:51-58)
-		__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][32 * SQ_PITCH];
+		__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][SQ_WORDS];
 		const int m = I.missing[c * 16 + l] - 2;
 		const int bias = m >= 0 ? 1 << m : 0;
 		int val[16];
