@@ -91,6 +91,7 @@ struct DWork {
 	unsigned *symbits;              // [n][BW] words, 2 bits per pass-1 symbol (one, sign)
 	unsigned short *tile_nonsig;    // [nplanes][NT] coefficients of the tile that are still insignificant
 	unsigned *tile_rank;            // [nplanes][MAX_PLANES][NT] insignificant coefficients before the tile, per plane
+	unsigned long long *count_base; // [nplanes][16] k_rank -> k_count: 1 + 2 * symbol base of the (plane, level)'s segment at the current bit plane, 0 = none
 	long BW;                        // bitmap words per image
 	int NT;
 	// speculative chunk parse (see k_spec): per 128-bit chunk of every stream
@@ -1265,7 +1266,10 @@ __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 	const int l = blockIdx.x;
 	const int plane = blockIdx.y;
 	const int img = plane / g.C, c = plane - img * g.C;
-	if (w.info[img].status || !w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p])
+	const int k1 = w.info[img].status ? 0 : w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
+	if (threadIdx.x == 0)   // k_count's tiles find their segment's symbols with one look-up
+		w.count_base[(long)plane * 16 + l] = k1 ? 1ull + 2ull * w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] : 0ull;
+	if (!k1)
 		return;
 	const int t0 = g.tile_first[l], nt = g.tile_first[l + 1] - t0;
 	const unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + t0;
@@ -1302,69 +1306,55 @@ __global__ __launch_bounds__(1024) void k_rank(UnpackGeom g, DWork w, int p)
 	}
 }
 
-// ones among the tile's symbols at plane p = popcount of its slice of the bitmap; 16 lanes share a
-// tile (a slice is at most 64 words).  Bit 31 of the tile's rank entry records "this plane turns
-// coefficients of this tile on" for k_apply_all.
-constexpr int COUNT_LANES = 16;
-
+// ones among the tile's symbols at plane p = popcount of its slice of the bitmap (at most 65 words).  One lane
+// per tile: its up to 17 16-byte loads are all in flight together, so a wave of 64 tiles pays one memory round
+// trip (16 lanes per tile meant sixteen times the waves, each waiting out two dependent round trips).  Bit 31 of
+// the tile's rank entry records "this plane turns coefficients of this tile on" for k_apply_all.
 __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 {
-	const int sub = threadIdx.x & (COUNT_LANES - 1);
-	const int tile = (blockIdx.x * blockDim.x + threadIdx.x) / COUNT_LANES;
+	const int tile = blockIdx.x * blockDim.x + threadIdx.x;
 	const int plane = blockIdx.y;
-	const int img = plane / g.C, c = plane - img * g.C;
-	bool live = tile < w.NT && !w.info[img].status;
-	int k1 = 0;
-	if (live) {
-		int l = 0;
-		while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
-			++l;
-		k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
-		live = k1 != 0;
-	}
+	const int img = plane / g.C;
+	if (tile >= w.NT)
+		return;
+	int l = 0;
+	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
+		++l;
+	const unsigned long long cb = w.count_base[(long)plane * 16 + l];
+	if (!cb)
+		return;
 	unsigned short *ns = w.tile_nonsig + (long)plane * w.NT + tile;
-	const unsigned n = live ? *ns : 0u;
-	live = live && n != 0;
-	unsigned ones = 0;
 	unsigned *rk = w.tile_rank + ((long)plane * MAX_PLANES + p) * w.NT + tile;
-	if (live) {
-		const unsigned *sym = w.symbits + img * w.BW;
-		const unsigned long long a = 2 * (w.seg_symbase[(long)img * MAX_SEGS + k1 - 1] + *rk);
-		const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
-		const long first = (long)(a >> 5), last = (long)((e - 1) >> 5);
-		// the slice is at most 65 words: every lane takes four consecutive ones (a 16-byte load) per round
-		for (long w0 = (first & ~3l) + 4 * sub; w0 <= last; w0 += 4 * COUNT_LANES) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(sym + w0);
-			const unsigned x[4] = { v.x, v.y, v.z, v.w };
+	const unsigned n = *ns;
+	if (!n)
+		return;
+	const unsigned *sym = w.symbits + img * w.BW;
+	const unsigned long long a = cb - 1ull + 2ull * *rk;
+	const unsigned long long e = a + 2ull * n;   // bit range [a, e), "one" flags on the even bits
+	const long first = (long)(a >> 5), last = (long)((e - 1) >> 5);
+	unsigned ones = 0;
+#pragma unroll 4
+	for (long w0 = first & ~3l; w0 <= last; w0 += 4) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(sym + w0);
+		const unsigned x[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const long wi = w0 + q;
-				unsigned m = x[q] & 0x55555555u;
-				if (wi < first || wi > last)
-					m = 0u;
-				if (wi == first)
-					m &= ~0u << (a & 31);
-				if (wi == last && (e & 31))
-					m &= (1u << (e & 31)) - 1u;
-				ones += (unsigned)__builtin_popcount(m);
-			}
+		for (int q = 0; q < 4; ++q) {
+			const long wi = w0 + q;
+			unsigned m = x[q] & 0x55555555u;
+			if (wi < first || wi > last)
+				m = 0u;
+			if (wi == first)
+				m &= ~0u << (a & 31);
+			if (wi == last && (e & 31))
+				m &= (1u << (e & 31)) - 1u;
+			ones += (unsigned)__builtin_popcount(m);
 		}
 	}
-	for (int o = COUNT_LANES / 2; o; o >>= 1)
-		ones += __shfl_xor(ones, o);
-	if (live && sub == 0 && ones) {
+	if (ones) {
 		*ns = (unsigned short)(n - ones);
 		*rk |= 0x80000000u;
 	}
 }
-
-// --------------------------------------------------------------- k_apply_all ---
-// One wave per tile, lane L owns coefficients 16L .. 16L+15, all planes in registers: 1024 coefficients
-// start at zero; for every plane (descending) the lane's still insignificant coefficients are CONSECUTIVE
-// pass-1 symbols (tile rank + insignificant coefficients in the lanes before: one DPP scan) and its
-// significant ones CONSECUTIVE refinement bits (index in ring - that count), so each lane fetches one
-// 32-bit window of the symbol bitmap and one of the stream's refinement block and hands the bits out to its
-// 16 coefficients in order.  The tile is written once, already in two's complement (decode.c:102-117 process()).
 
 // Handing bits out to the coefficients of a lane, four coefficients per table look-up.
 // DEP_SYM[m][s]: m = 4-bit mask of coefficients that take a pass-1 symbol, s = the next four symbols (two bits
@@ -1712,6 +1702,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		off = 0;
 		const size_t o_ts = take(sizeof(short) * (size_t)nplanes * NT);
 		const size_t o_tr = take(sizeof(unsigned) * (size_t)nplanes * MAX_PLANES * NT);
+		const size_t o_cb = take(sizeof(unsigned long long) * (size_t)nplanes * 16);
 		char *tiles = (char *)dwtx_scratch(ctx, SLOT_UP_TILES, off);
 		if (!small || !bits || !tiles)
 			return DWTX_ERR_NOMEM;
@@ -1725,6 +1716,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		w.symbits = bits;
 		w.tile_nonsig = (unsigned short *)(tiles + o_ts);
 		w.tile_rank = (unsigned *)(tiles + o_tr);
+		w.count_base = (unsigned long long *)(tiles + o_cb);
 		// speculative chunk tables
 		w.NCH = (long)((stream_stride * 8 + CH_BITS - 1) / CH_BITS);
 		w.NCH = (w.NCH + 1 + 3) / 4 * 4 - 1;   // NCH+1 table rows per stream, a multiple of 4 for the vectorised scans
@@ -1811,6 +1803,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		h.symbits += (size_t)i0 * w.BW;
 		h.tile_nonsig += (size_t)i0 * C * NT;
 		h.tile_rank += (size_t)i0 * C * MAX_PLANES * NT;
+		h.count_base += (size_t)i0 * C * 16;
 		h.exitX += (size_t)i0 * FAM * w.NCH;
 		h.entryE += (size_t)i0 * FAM * w.NCH;
 		h.cs += (size_t)i0 * FAM * (w.NCH + 1);
@@ -1878,7 +1871,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 				pmax = host_info[i].pmax;
 		for (int p = pmax - 1; p >= 0; --p) {
 			hipLaunchKernelGGL(k_rank, dim3(g.levels, cnt * C), dim3(1024), 0, st, g, h, p);
-			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT * COUNT_LANES, 256), cnt * C), dim3(256), 0, st, g, h, p);
+			hipLaunchKernelGGL(k_count, dim3(dwtx_cdiv(NT, 256), cnt * C), dim3(256), 0, st, g, h, p);
 		}
 		// Whole-resolution images only (decode.c:251-254: a stream that ends early gives a smaller picture, whose
 		// pyramid has another pitch): then reconstruction() of the square levels happens inside k_apply_all.
