@@ -233,9 +233,24 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
-	__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][SQ_WORDS];
 	int val[16];
-	load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, sq_lds[threadIdx.x >> 6], val);
+	if ((g.sq_levels >> l) & 1u) {
+		// the tile is a 32x32 square of the pyramid (hilbert_dev.h); a histogram does not care about the order:
+		// every lane takes four consecutive coefficients of four rows
+		const SquareMap m = square_map(g.side[l], (unsigned)(((unsigned long)g.side[l] * (unsigned long)g.side[l]) >> 12) +
+			(unsigned)(tile - g.tile_first[l]));
+		const int *sq = g.pyr + (long)plane * g.total + (long)(m.my & ~31u) * g.W + (m.mx & ~31u);
+#pragma unroll
+		for (int it = 0; it < 4; ++it) {
+			const int4 v4 = *reinterpret_cast<const int4 *>(sq + (long)(it * 8 + (lane >> 3)) * g.W + (lane & 7) * 4);
+			val[4 * it] = v4.x;
+			val[4 * it + 1] = v4.y;
+			val[4 * it + 2] = v4.z;
+			val[4 * it + 3] = v4.w;
+		}
+	} else {
+		load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, nullptr, val);
+	}
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 	unsigned long long Ra = 0, Rb = 0;
 	unsigned mx = 0;
