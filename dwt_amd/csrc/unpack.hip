@@ -416,7 +416,10 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
 		// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
 		// number of bits apart cannot meet while the order stays 0: seed both parities.
-		int off = vs % FAM, o = 0;
+		// The warm-up only has to run long enough for the speculative path to fall in with the true one: starting in
+		// the middle of the chunk halves this kernel and costs the relaxation rounds a little (starting at three
+		// quarters costs them more than it saves); the walker sees the same stitched runs.
+		int off = CH_BITS / 2 + vs % FAM, o = 0;
 		const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
 		const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
 		w.exitX[vs * w.NCH + chunk] = out;
