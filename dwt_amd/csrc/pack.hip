@@ -791,32 +791,29 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	}
 	wave_sync();
 
-	// ---- tokens out, slot-parallel (two slots per lane): run = zeros since the previous one of the same plane in this tile ----
+	// ---- tokens out, plane by plane (a plane's tokens are consecutive slots and consecutive in the stream):
+	//      run = zeros since the previous one of the same plane in this tile ----
 	{
 		unsigned short *tok16 = w.tok16 + img * w.TS;
-		const int nt = nvalid - (int)L.cum[0];   // non-zero coefficients = tokens of the tile
-		const unsigned *zs2 = reinterpret_cast<const unsigned *>(L.zs);
-		unsigned carry = 0;                      // slot 128r-1 (in the high half)
-		for (int r = 0; r * 128 < nt; ++r) {
-			const int s0 = r * 128 + 2 * lane;
-			const unsigned a2 = s0 < nt ? zs2[s0 >> 1] : 0u;
-			const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp((int)carry, (int)a2, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps carry
-			carry = (unsigned)__builtin_amdgcn_readlane((int)a2, 63);
-			const unsigned a0 = a2 & 0xffffu, a1 = a2 >> 16, bp = b2 >> 16;
-			// a plane's tokens are consecutive slots: the first one of a plane is where the plane changes
-			if (s0 < nt) {
-				const unsigned z = a0 & 0x3ffu, p = a0 >> 12;
-				const unsigned run = s0 == 0 || (bp >> 12) != p ? z : z - (bp & 0x3ffu);
-				const unsigned gb = L.gb[p];
-				if (gb != ~0u)
-					tok16[gb + (unsigned)s0] = (unsigned short)(run | ((a0 >> 10) & 1u) << 12);
-			}
-			if (s0 + 1 < nt) {
-				const unsigned z = a1 & 0x3ffu, p = a1 >> 12;
-				const unsigned run = (a0 >> 12) != p ? z : z - (a0 & 0x3ffu);
-				const unsigned gb = L.gb[p];
-				if (gb != ~0u)
-					tok16[gb + (unsigned)s0 + 1u] = (unsigned short)(run | ((a1 >> 10) & 1u) << 12);
+		for (int p = P > 0 ? P - 1 : 0; p >= 0; --p) {
+			const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p]), c1 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p + 1]);
+			const int ones = (int)(c1 - c0);
+			const unsigned gb = (unsigned)__builtin_amdgcn_readfirstlane((int)L.gb[p]);
+			if (ones <= 0 || gb == ~0u)
+				continue;   // uniform
+			const int slot0 = nvalid - (int)c1;
+			unsigned short *dst = tok16 + gb + (unsigned)slot0;
+			unsigned carry = 0;   // the slot before this round's first one
+			for (int k0 = 0; k0 < ones; k0 += 64) {
+				const int k = k0 + lane;
+				const unsigned a = k < ones ? L.zs[slot0 + k] : 0u;
+				const unsigned b = (unsigned)__builtin_amdgcn_update_dpp((int)carry, (int)a, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps carry
+				carry = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+				if (k < ones) {
+					const unsigned z = a & 0x3ffu;
+					const unsigned run = k ? z - (b & 0x3ffu) : z;
+					dst[k] = (unsigned short)(run | ((a >> 10) & 1u) << 12);
+				}
 			}
 		}
 		// zeros after the tile's last one of each plane: what the tile hands to the run counter (k_carry_*)
