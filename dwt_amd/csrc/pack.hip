@@ -98,7 +98,6 @@ struct RunMap {
 struct Work {
 	// per plane
 	unsigned short *cum;        // [nplanes][NT][32]
-	int *planes_dev;            // [nplanes]
 	// per image
 	ImgInfo *info;              // [n]
 	int *seg_desc;              // [n][MAX_SEGS]   c | l<<4 | (p+1)<<8
@@ -196,14 +195,52 @@ __device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__rest
 		return;
 	}
 	const int *src = lin + (long)plane * g.total + g.pixels[l] + (long)j * TILE + 16 * lane;
-	if (nvalid == TILE) {
+	// A ring starts wherever the levels before it end: its tiles are 16-byte aligned only by luck (always for
+	// power-of-two shapes).  A 16-byte load from a 4-byte aligned address is split up by the memory pipeline, so
+	// an unaligned tile is read as five aligned quads around the lane's 16 coefficients and shifted in registers
+	// by the ring's (uniform) misalignment.  The quad after a ring's last tile may lie outside the buffer: that
+	// tile takes the scalar path.
+	const int k = (int)(((uintptr_t)src >> 2) & 3);   // uniform: lanes are 64 bytes apart
+	const bool last_of_ring = g.pixels[l] + (long)(j + 1) * TILE >= g.pixels[l + 1];
+	if (nvalid == TILE && (k == 0 || !last_of_ring)) {
+		const int4 *A = reinterpret_cast<const int4 *>(src - k);
+		int t[20];
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
-			const Int4U v4 = *reinterpret_cast<const Int4U *>(src + 4 * q);
-			val[4 * q] = v4.x;
-			val[4 * q + 1] = v4.y;
-			val[4 * q + 2] = v4.z;
-			val[4 * q + 3] = v4.w;
+			const int4 v4 = A[q];
+			t[4 * q] = v4.x;
+			t[4 * q + 1] = v4.y;
+			t[4 * q + 2] = v4.z;
+			t[4 * q + 3] = v4.w;
+		}
+		t[16] = t[17] = t[18] = t[19] = 0;
+		if (k) {
+			const int4 v4 = A[4];
+			t[16] = v4.x;
+			t[17] = v4.y;
+			t[18] = v4.z;
+		}
+		switch (k) {
+		case 0:
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				val[i] = t[i];
+			break;
+		case 1:
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				val[i] = t[i + 1];
+			break;
+		case 2:
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				val[i] = t[i + 2];
+			break;
+		default:
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				val[i] = t[i + 3];
+			break;
 		}
 	} else {
 #pragma unroll
@@ -231,9 +268,8 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)(tile - g.tile_first[l]) * TILE;
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
-	const int first = 16 * lane;
-	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;
 	int val[16];
+	unsigned ok = 0xffffu;
 	if ((g.sq_levels >> l) & 1u) {
 		// the tile is a 32x32 square of the pyramid (hilbert_dev.h); a histogram does not care about the order:
 		// every lane takes four consecutive coefficients of four rows
@@ -249,7 +285,26 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 			val[4 * it + 3] = v4.w;
 		}
 	} else {
-		load_tile16(g, lin, plane, l, tile - g.tile_first[l], lane, nvalid, nv, nullptr, val);
+		// the same freedom on the linearised plane: the wave reads the tile front to back (lane-serial loads,
+		// 64 bytes apart, touch every cache line of the tile four times).  ok = which of the 16 exist.
+		const int *src = lin + (long)plane * g.total + base;
+		if (nvalid == TILE && (((uintptr_t)src >> 2) & 3) == 0) {
+#pragma unroll
+			for (int it = 0; it < 4; ++it) {
+				const int4 v4 = reinterpret_cast<const int4 *>(src)[it * 64 + lane];
+				val[4 * it] = v4.x;
+				val[4 * it + 1] = v4.y;
+				val[4 * it + 2] = v4.z;
+				val[4 * it + 3] = v4.w;
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int e = i * 64 + lane;
+				val[i] = e < nvalid ? src[e] : 0;
+				ok &= ~((e < nvalid ? 0u : 1u) << i);
+			}
+		}
 	}
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 	unsigned long long Ra = 0, Rb = 0;
@@ -260,7 +315,7 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 		const unsigned a = (unsigned)(v < 0 ? -v : v);
 		mx |= a;
 		int t = a ? 32 - __builtin_clz(a) : 0;
-		t = i < nv ? t : 16;   // past the ring's end: counted nowhere
+		t = (ok >> i) & 1u ? t : 16;   // past the ring's end: counted nowhere
 		const unsigned long long m = t < 16 ? ONES << (4 * t) : 0ull;
 		if (i < 8)
 			Ra += m;
@@ -282,14 +337,13 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 		*reinterpret_cast<uint4 *>(cum) = make_uint4(D[0], D[1], D[2], D[3]);
 		*reinterpret_cast<uint4 *>(cum + 8) = make_uint4(D[4], D[5], D[6], D[7]);
 	} else if (lane >= 16 && lane < NCUM) {
-		cum[lane] = (unsigned short)nvalid;   // |v| < 2^16 for every stream this coder accepts (k_plan checks the plane count)
+		// |v| < 2^16 for every stream this coder accepts (k_plan checks the plane count)
+		// The last entry is the tile's own bit-plane count, 1 + ilog2(max |v|): k_plan takes the maximum over the
+		// plane's tiles (encode.c:130, over the detail rings only, encode.c:165).  (An atomicMax per tile on one
+		// word per plane, even filtered by a plain read first, serialises at the memory side: the eight XCDs' L2s
+		// cannot hold a device-coherent word, and that cost 0.7 ms per 400 000 tiles.)
+		cum[lane] = (unsigned short)(lane == NCUM - 1 ? (mx ? ilog2u(mx) + 1 : 0) : nvalid);
 	}
-	// planes = 1 + ilog2(max |v|) (encode.c:130), over the detail rings only (encode.c:165)
-	// 100k waves hammering one word per plane would serialise in L2: the value only grows, so a
-	// (possibly stale) plain read filters out all but the first few
-	const int top = mx ? ilog2u(mx) + 1 : 0;
-	if (lane == 0 && top > __hip_atomic_load(w.planes_dev + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-		atomicMax(w.planes_dev + plane, top);
 }
 
 // ------------------------------------------------------------------ k_plan ---
@@ -363,14 +417,29 @@ struct HdrWriter {
 
 __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words, long capacity)
 {
+	const int img = blockIdx.x;
+	__shared__ int top_of[3];
+	if (threadIdx.x < 3)
+		top_of[threadIdx.x] = 0;
+	__syncthreads();
+	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count: maximum over its tiles (k_hist left one value per tile)
+		const unsigned short *cum = w.cum + (long)(img * g.C + c) * w.NT * NCUM + (NCUM - 1);
+		int top = 0;
+		for (int t = threadIdx.x; t < w.NT; t += blockDim.x)
+			top = max(top, (int)cum[(long)t * NCUM]);
+		for (int o = 32; o; o >>= 1)
+			top = max(top, __shfl_xor(top, o));
+		if ((threadIdx.x & 63) == 0)
+			atomicMax(&top_of[c], top);
+	}
+	__syncthreads();
 	if (threadIdx.x)
 		return;
-	const int img = blockIdx.x;
 	ImgInfo &I = w.info[img];
 	int planes[3] = { 0, 0, 0 };
 	int pmax = 0;
 	for (int c = 0; c < g.C; ++c) {
-		planes[c] = w.planes_dev[img * g.C + c];
+		planes[c] = top_of[c];
 		pmax = planes[c] > pmax ? planes[c] : pmax;
 		I.planes[c] = planes[c];
 	}
@@ -1868,7 +1937,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b);
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-		const size_t o_planes = take(sizeof(int) * nplanes);
 		const size_t o_info = take(sizeof(ImgInfo) * n);
 		const size_t o_slow = take(sizeof(int) * n);
 		const size_t o_sbits = take(sizeof(unsigned long long) * n);
@@ -1882,7 +1950,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
 		if (!w.cum || !small)
 			return DWTX_ERR_NOMEM;
-		w.planes_dev = (int *)(small + o_planes);
 		w.info = (ImgInfo *)(small + o_info);
 		w.slow = (int *)(small + o_slow);
 		w.stream_bits = (unsigned long long *)(small + o_sbits);
@@ -1958,7 +2025,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	// cleared by k_clear_stream once its length is known
 
 	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
-	hipLaunchKernelGGL(k_plan, dim3(n), dim3(64), 0, s, g, lin, w, outw, out_words, capacity);
+	hipLaunchKernelGGL(k_plan, dim3(n), dim3(256), 0, s, g, lin, w, outw, out_words, capacity);
 	hipLaunchKernelGGL(k_entries_count, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, g, w);
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
