@@ -255,21 +255,17 @@ __device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__rest
 // nibbles (two registers of eight coefficients each: a nibble holds up to 8); the lane totals, widened
 // to 16-bit fields, are summed over the wave with DPP adds.
 
-__global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
+// the loads of one tile (issued, not waited for); ok = which of the lane's 16 values exist
+__device__ __forceinline__ void hist_load(const PackGeom &g, const int *__restrict__ lin, int plane, int tile, int lane, int (&val)[16],
+	unsigned &ok, int &nvalid)
 {
-	const int lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int plane = blockIdx.y;
-	if (tile >= w.NT)
-		return;
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
 	const long ring1 = g.pixels[l + 1];
 	const long base = g.pixels[l] + (long)(tile - g.tile_first[l]) * TILE;
-	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
-	int val[16];
-	unsigned ok = 0xffffu;
+	nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	ok = 0xffffu;
 	if ((g.sq_levels >> l) & 1u) {
 		// the tile is a 32x32 square of the pyramid (hilbert_dev.h); a histogram does not care about the order:
 		// every lane takes four consecutive coefficients of four rows
@@ -306,6 +302,10 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 			}
 		}
 	}
+}
+
+__device__ __forceinline__ void hist_finish(const Work &w, int plane, int tile, int lane, const int (&val)[16], unsigned ok, int nvalid)
+{
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 	unsigned long long Ra = 0, Rb = 0;
 	unsigned mx = 0;
@@ -346,6 +346,28 @@ __global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict_
 	}
 }
 
+// Two tiles per wave: both tiles' loads are in flight before the first is counted (the kernel only waits for memory).
+constexpr int HIST_TPW = 2;
+
+__global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
+{
+	const int lane = threadIdx.x & 63;
+	const int tile0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * HIST_TPW;
+	const int plane = blockIdx.y;
+	if (tile0 >= w.NT)
+		return;
+	int val[HIST_TPW][16], nvalid[HIST_TPW];
+	unsigned ok[HIST_TPW];
+#pragma unroll
+	for (int u = 0; u < HIST_TPW; ++u)
+		if (tile0 + u < w.NT)   // uniform
+			hist_load(g, lin, plane, tile0 + u, lane, val[u], ok[u], nvalid[u]);
+#pragma unroll
+	for (int u = 0; u < HIST_TPW; ++u)
+		if (tile0 + u < w.NT)
+			hist_finish(w, plane, tile0 + u, lane, val[u], ok[u], nvalid[u]);
+}
+
 // ------------------------------------------------------------------ k_plan ---
 
 struct HdrWriter {
@@ -366,6 +388,8 @@ struct HdrWriter {
 		if (nb <= 0)
 			return true;
 		rc_n += nb;
+		if (rc_cap <= 0)   // no limit: nothing is ever refused, rc_count() only needs the sum
+			return true;
 		while (rc_n >= 8) {
 			if (rc_cap > 0 && rc_len >= rc_cap) {
 				rc_n = 0;
@@ -415,7 +439,7 @@ struct HdrWriter {
 	__device__ unsigned bits() const { return (unsigned)(pos * 32 + n); }
 };
 
-__global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words, long capacity)
+__global__ __launch_bounds__(1024) void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned *out, long out_words, long capacity)
 {
 	const int img = blockIdx.x;
 	__shared__ int top_of[3];
@@ -425,13 +449,34 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count: maximum over its tiles (k_hist left one value per tile)
 		const unsigned short *cum = w.cum + (long)(img * g.C + c) * w.NT * NCUM + (NCUM - 1);
 		int top = 0;
-		for (int t = threadIdx.x; t < w.NT; t += blockDim.x)
-			top = max(top, (int)cum[(long)t * NCUM]);
+		for (int t0 = threadIdx.x; t0 < w.NT; t0 += 8 * blockDim.x) {   // eight loads in flight, not one after the other
+			unsigned short v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int t = t0 + u * (int)blockDim.x;
+				v[u] = t < w.NT ? cum[(long)t * NCUM] : (unsigned short)0;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				top = max(top, (int)v[u]);
+		}
 		for (int o = 32; o; o >>= 1)
 			top = max(top, __shfl_xor(top, o));
 		if ((threadIdx.x & 63) == 0)
 			atomicMax(&top_of[c], top);
 	}
+	// the rest is one thread's work (a few thousand dependent steps): what it reads comes to LDS first (its own
+	// loads would each wait out the memory latency, having stores in between), what it would clear is cleared here
+	constexpr int ROOT_MAX = 256;   // root images are at most 15x15 (the last level leaves 8..15 per side)
+	__shared__ int root[3 * ROOT_MAX];
+	const bool root_lds = g.pixels[0] <= ROOT_MAX;
+	if (root_lds)
+		for (int i = threadIdx.x; i < g.C * g.pixels[0]; i += blockDim.x) {
+			const int c = i / g.pixels[0];
+			root[c * ROOT_MAX + i - c * g.pixels[0]] = lin[(long)(img * g.C + c) * g.total + i - c * g.pixels[0]];
+		}
+	for (int i = threadIdx.x; i < 48 * MAX_PLANES; i += blockDim.x)
+		w.segidx[(long)img * 48 * MAX_PLANES + i] = 0;
 	__syncthreads();
 	if (threadIdx.x)
 		return;
@@ -465,7 +510,7 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 	I.meta_bits = hw.rc_count();   // encode.c:175-176
 	// encode.c:97-110 root image per channel
 	for (int c = 0; c < g.C; ++c) {
-		const int *r = lin + (long)(img * g.C + c) * g.total;
+		const int *r = root_lds ? root + c * ROOT_MAX : lin + (long)(img * g.C + c) * g.total;
 		unsigned mx = 0;
 		for (int i = 0; i < g.pixels[0]; ++i) {
 			const int v = r[i];
@@ -496,8 +541,6 @@ __global__ void k_plan(PackGeom g, const int *__restrict__ lin, Work w, unsigned
 	int *sd = w.seg_desc + (long)img * MAX_SEGS;
 	int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
 	int *sx = w.segidx + (long)img * 48 * MAX_PLANES;
-	for (int i = 0; i < 48 * MAX_PLANES; ++i)
-		sx[i] = 0;
 	int K = 0, E = 0;
 	auto add = [&](int c, int l, int p) {
 		if (K >= MAX_SEGS)
@@ -584,7 +627,10 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_count(PackGeom g, Work w)
 	if ((int)blockIdx.x * ENT_BLOCK >= E)
 		return;
 	const int *sd = w.seg_desc + (long)img * MAX_SEGS;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	__shared__ int eb[MAX_SEGS + 1];   // the entry -> segment search reads it seven times in a row
+	for (int k = threadIdx.x; k <= K; k += ENT_BLOCK)
+		eb[k] = w.seg_ebase[(long)img * (MAX_SEGS + 1) + k];
+	__syncthreads();
 	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
 	unsigned nt = 0, nr = 0;
 	if (e < E) {
@@ -1832,20 +1878,32 @@ __global__ __launch_bounds__(256) void k_refcopy(Work w, unsigned *out, long out
 	const unsigned long long total = sst[K];
 	const unsigned *stage = w.stage + img * w.SW;
 	unsigned *dst = out + img * out_words;
+	// every word looks its segment up (a binary search over the segments' first staging words, then the segment's
+	// size and place in the stream): from LDS, seven dependent reads from memory per word were most of this kernel
+	__shared__ unsigned long long l_sst[MAX_SEGS + 1], l_off[MAX_SEGS];
+	__shared__ unsigned l_refs[MAX_SEGS];
+	for (int k = threadIdx.x; k <= K; k += blockDim.x) {
+		l_sst[k] = sst[k];
+		if (k < K) {
+			l_refs[k] = w.seg_refs[(long)img * MAX_SEGS + k];
+			l_off[k] = w.seg_rawoff[(long)img * MAX_SEGS + k];
+		}
+	}
+	__syncthreads();
 	for (unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total;
 		wi += (unsigned long long)gridDim.x * blockDim.x) {
 		int lo = 0, hi = K - 1;   // the segment whose block holds staging word wi: largest k with sst[k] <= wi
 		while (lo < hi) {
 			const int mid = (lo + hi + 1) >> 1;
-			if (sst[mid] <= wi)
+			if (l_sst[mid] <= wi)
 				lo = mid;
 			else
 				hi = mid - 1;
 		}
 		const int k = lo;
-		const unsigned long i = (unsigned long)(wi - sst[k]);
-		const unsigned n = w.seg_refs[(long)img * MAX_SEGS + k];
-		const unsigned long long D = w.seg_rawoff[(long)img * MAX_SEGS + k];
+		const unsigned long i = (unsigned long)(wi - l_sst[k]);
+		const unsigned n = l_refs[k];
+		const unsigned long long D = l_off[k];
 		const int sh = (int)(D & 31);
 		const long d0 = (long)(D >> 5);
 		const unsigned long cw = ((unsigned long)n + 31) >> 5;            // staging words of the block
@@ -2024,8 +2082,8 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	// k_plan stores the first words (header, root image, plane counts) outright; the rest of the stream is
 	// cleared by k_clear_stream once its length is known
 
-	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
-	hipLaunchKernelGGL(k_plan, dim3(n), dim3(256), 0, s, g, lin, w, outw, out_words, capacity);
+	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4 * HIST_TPW), nplanes), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_plan, dim3(n), dim3(1024), 0, s, g, lin, w, outw, out_words, capacity);
 	hipLaunchKernelGGL(k_entries_count, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, g, w);
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
@@ -2047,7 +2105,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		hipLaunchKernelGGL(k_clear_stream, dim3((unsigned)(cb < 1024 ? cb : 1024), n), dim3(256), 0, s, w, outw, out_words);
 	}
 	hipLaunchKernelGGL(k_emit, dim3((unsigned)((w.TS / CHUNK + 1 + 3) / 4), n), dim3(256), 0, s, w, outw, out_words);
-	hipLaunchKernelGGL(k_refcopy, dim3(1024, n), dim3(256), 0, s, w, outw, out_words);
+	hipLaunchKernelGGL(k_refcopy, dim3(256, n), dim3(256), 0, s, w, outw, out_words);
 	DWTX_LAUNCH_CHECK();
 	static_assert(sizeof(dwtx_stream_info) == sizeof(ImgInfo), "ImgInfo is the device image of dwtx_stream_info");
 	DWTX_HIP(hipMemcpyAsync(dev_info, w.info, sizeof(ImgInfo) * (size_t)n, hipMemcpyDeviceToDevice, s));
