@@ -116,7 +116,11 @@ struct DWork {
 	int *nch;                       // [n] chunks that hold stream bytes (rounded so that nch+1 is a multiple of 4), <= NCH
 	long NCH, NB;
 	long MAX_HOPS;
+	int fam;                        // families in use this pass: 1 (the usual case) or FAM (see k_spec); the tables keep FAM rows per image either way
 };
+
+// grid row -> virtual stream (image * FAM + family) when only w.fam of the FAM families run
+__device__ __forceinline__ int vstream(const DWork &w, int row) { return (row / w.fam) * FAM + row % w.fam; }
 
 __device__ __forceinline__ int popc_below(unsigned long long m)
 {
@@ -408,7 +412,7 @@ constexpr int CHUNK_GRID = 2048;
 
 __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const int vs = blockIdx.y, img = vs / FAM;   // virtual stream = (image, family)
+	const int vs = vstream(w, blockIdx.y), img = vs / FAM;   // virtual stream = (image, family)
 	const long nch = w.nch[img];
 	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
 		if (chunk >= nch)
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *stre
 		// The warm-up only has to run long enough for the speculative path to fall in with the true one: starting in
 		// the middle of the chunk halves this kernel and costs the relaxation rounds a little (starting at three
 		// quarters costs them more than it saves); the walker sees the same stitched runs.
-		int off = CH_BITS / 2 + vs % FAM, o = 0;
+		int off = (w.fam == 1 ? 0 : CH_BITS / 2) + vs % FAM, o = 0;
 		const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
 		const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
 		w.exitX[vs * w.NCH + chunk] = out;
@@ -490,7 +494,7 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 // round 1: every chunk; a chunk whose exit moved hands its successor to the work list
 __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const int vs = blockIdx.y;
+	const int vs = vstream(w, blockIdx.y);
 	const long nch = w.nch[vs / FAM];
 	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
 		bool moved = false;
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *
 // those records are never used, so the rounds are simply cut off (LINK_ROUNDS)
 __global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
 {
-	const int vs = blockIdx.y, shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
+	const int vs = vstream(w, blockIdx.y), shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
 		parts = gridDim.x / LINK_SHARDS;
 	const unsigned count = w.todo_count[round * w.todo_round + vs * LINK_SHARDS + shard];
 	const unsigned *list = w.todo[cur] + ((long)vs * LINK_SHARDS + shard) * w.todo_cap;
@@ -599,7 +603,7 @@ constexpr int SCAN_GRID = 1024;
 __global__ __launch_bounds__(256) void k_scan_local(DWork w)
 {
 	__shared__ Tri wsum[4];
-	const int vs = blockIdx.y;   // virtual stream
+	const int vs = vstream(w, blockIdx.y);   // virtual stream
 	const long n = w.NCH + 1, nch = w.nch[vs / FAM], used = nch + 1;
 	unsigned short *exitX = w.exitX + (long)vs * w.NCH, *entryE = w.entryE + (long)vs * w.NCH;
 	for (long vb = blockIdx.x; vb * SCAN_BLOCK < used; vb += gridDim.x) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void k_scan_local(DWork w)
 __global__ __launch_bounds__(256) void k_scan_parts(DWork w)
 {
 	__shared__ Tri wsum[4];
-	const int img = blockIdx.x;   // virtual stream
+	const int img = vstream(w, blockIdx.x);   // virtual stream
 	const long nb = (w.nch[img / FAM] + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;   // blocks k_scan_local ran
 	Tri carry = { 0, 0, 0 };
 	for (long b0 = 0; b0 < nb; b0 += 256) {
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(256) void k_scan_parts(DWork w)
 // adds the block offsets and files the unjoined chunks: the one with rank r (= cg[i], exclusive prefix) goes to breaks[r]
 __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 {
-	const int vs = blockIdx.y;   // virtual stream
+	const int vs = vstream(w, blockIdx.y);   // virtual stream
 	const long n = w.NCH + 1, nch = w.nch[vs / FAM], used = nch + 1;
 	const unsigned short *flags = w.entryE + (long)vs * w.NCH;
 	unsigned *breaks = w.breaks + (long)vs * w.NCH;
@@ -918,7 +922,27 @@ __global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *s
 	}
 }
 
+// A part of the batch is walked again (with both families): what the first attempt left behind and the call's
+// initial clears covered goes back to zero — the work-list counters of every round, the hop count, the walker's
+// per-image records.  (The symbol bitmap is cleared beside this.)
+__global__ __launch_bounds__(256) void k_part_reset(DWork h, int cnt)
+{
+	const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	const long per_round = (long)cnt * FAM * LINK_SHARDS;
+	if (t < per_round)
+		for (int r = 0; r < LINK_ROUNDS + 2; ++r)
+			h.todo_count[r * h.todo_round + t] = 0u;
+	if (t < cnt)
+		h.nhops[t] = 0;
+	if (t < (long)cnt * 48 * MAX_PLANES)
+		h.segidx[t] = 0;
+	if (t < (long)cnt * (long)(sizeof(DecInfo) / sizeof(int)))
+		reinterpret_cast<int *>(h.info)[t] = 0;
+}
+
 // --------------------------------------------------------------- k_tokenize ---
+
+constexpr unsigned WALK_GAVE_UP = 0xffffffffu;   // DecInfo::hops of an image whose one-family walk was abandoned
 
 __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
 	const unsigned long long *lens, int *lin, int n)
@@ -1014,7 +1038,18 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	const unsigned long long *s64 = (const unsigned long long *)s8;
 	// chunk i is safe to parse blindly if every token starting in it ends inside the data
 	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
-	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter(), n_fast = 0;
+#ifdef DWTX_DEBUG_HOOKS   // cycle counters for tools/dbg_walker.py (s_memtime waits on the scalar memory counter: not in the product)
+	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter(), t_mark = 0;
+#define WALK_MARK() t_mark = __builtin_readcyclecounter()
+#define WALK_ADD(acc) do { const unsigned long long t_now = __builtin_readcyclecounter(); acc += t_now - t_mark; t_mark = t_now; } while (0)
+#else
+#define WALK_MARK()
+#define WALK_ADD(acc)
+#endif
+	// With one family the walk can meet a stretch that the recorded paths do not follow at all (k_spec): it gives
+	// up when the chunks it parses by hand pile up, and the host repeats the part with both families.
+	unsigned scans = 0, streak = 0;
+	bool giveup = false;
 	long checked = -1;
 	int nhops = 0;
 	unsigned hopped = 0, walked = 0;
@@ -1041,6 +1076,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			sidx[(c * 16 + l) * MAX_PLANES + p] = k + 1;
 		int q = 0, ones = 0;
 		bool ok = true;
+		streak = 0;
 		while (q < n1) {
 			unsigned zr;
 			if (cnt == 0) {   // rle.h:70-75: a token starts here
@@ -1049,10 +1085,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					const unsigned need = (unsigned)(n1 - q);
 					const int rel = (int)(br.b - ((unsigned long long)ci << CH_LOG2));
 					bool moved = false;
-					const unsigned long long tq0 = __builtin_readcyclecounter();
+					WALK_MARK();
 					if (ci != checked) {
 						checked = ci;
-						for (int fam = 0; fam < FAM && !moved; ++fam) {
+						for (int fam = 0; fam < w.fam && !moved; ++fam) {
 							const unsigned ep = exitX0[fam * w.NCH + ci - 1];
 							if (ep == 0xffffu || (int)(ep & 0xffu) != rel || (int)(ep >> 8) != order)
 								continue;
@@ -1104,11 +1140,17 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							}
 						}
 					}
-					const unsigned long long tq1 = __builtin_readcyclecounter();
-					t_hop += tq1 - tq0;
+					WALK_ADD(t_hop);
+					if (moved)
+						streak = 0;
 					if (!moved) {
 						// parse the rest of this chunk ourselves, counting only; k_hopbits sets the bits later
-						++n_fast;
+						++scans;
+						++streak;
+						if (w.fam < FAM && (streak > 48u || scans > 256u + 16u * (unsigned)nsegs + (unsigned)(lastsafe >> 9))) {
+							giveup = true;
+							return false;
+						}
 						const ChunkScan cs = chunk_scan(chunk_load(s64, br.n64, ci), rel, order, need);
 						const unsigned tok = cs.tok, sym = cs.sym;
 						const int off = cs.off, o = cs.o;
@@ -1129,7 +1171,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							moved = true;
 						}
 					}
-					t_fast += __builtin_readcyclecounter() - tq1;
+					WALK_ADD(t_fast);
 					if (moved)
 						continue;
 				}
@@ -1243,12 +1285,19 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		}
 	}
 	bm.flush();
+	if (giveup) {   // nothing of this walk is used: no records for k_hopbits, the marker for the host
+		w.nhops[img] = 0;
+		I.hops = WALK_GAVE_UP;
+		return;
+	}
 	w.nhops[img] = nhops;
 	I.hops = (unsigned)nhops;
 	I.hopped_chunks = hopped;
 	I.walked_tokens = walked;
 	I.zeros_left = cnt;
-	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; w.dbg[img * 4 + 3] = n_fast; }
+#ifdef DWTX_DEBUG_HOOKS
+	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; w.dbg[img * 4 + 3] = scans; }
+#endif
 	I.level = level;
 	I.nsegs = nsegs;
 	I.truncated = stop ? (eof ? 3 : 1) : 0;
@@ -1726,6 +1775,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		w.NB = (w.NCH + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
 		off = 0;
 		w.MAX_HOPS = 8 * MAX_SEGS + w.NCH / 8;
+		w.fam = 1;
 		const size_t o_ep = take(sizeof(short) * (size_t)n * FAM * w.NCH);
 		const size_t o_eq = take(sizeof(short) * (size_t)n * FAM * w.NCH);
 		const size_t o_cs = take(sizeof(unsigned long long) * (size_t)n * FAM * (w.NCH + 1));
@@ -1832,27 +1882,29 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		return h;
 	};
 	// chunk tables; then (walk) token walk and symbol bits of the hopped-over chunks
-	auto pre = [&](hipStream_t st, int i0, int cnt) -> int {
-		const DWork h = slice(i0);
+	auto pre = [&](hipStream_t st, int i0, int cnt, int fam) -> int {
+		DWork h = slice(i0);
+		h.fam = fam;
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		const unsigned cblocks = (unsigned)((w.NCH + 1 + 255) / 256);
-		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * FAM);
+		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * h.fam);
 		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
 		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills the list of chunks to redo
 		int cur = 1;
 		for (int r = 2; r <= LINK_ROUNDS; ++r) {   // the lists shrink: fewer workgroups per shard after the first rounds
-			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * (r <= 3 ? 4 : 1), cnt * FAM), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
+			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * (r <= 3 ? 4 : 1), cnt * h.fam), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
 			cur ^= 1;
 		}
 		const unsigned sblocks = (unsigned)(w.NB < SCAN_GRID ? w.NB : SCAN_GRID);
-		hipLaunchKernelGGL(k_scan_local, dim3(sblocks, cnt * FAM), dim3(256), 0, st, h);
-		hipLaunchKernelGGL(k_scan_parts, dim3(cnt * FAM), dim3(256), 0, st, h);
-		hipLaunchKernelGGL(k_scan_add, dim3(sblocks, cnt * FAM), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_local, dim3(sblocks, cnt * h.fam), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_parts, dim3(cnt * h.fam), dim3(256), 0, st, h);
+		hipLaunchKernelGGL(k_scan_add, dim3(sblocks, cnt * h.fam), dim3(256), 0, st, h);
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
 	};
-	auto walk = [&](hipStream_t st, int i0, int cnt) -> int {
-		const DWork h = slice(i0);
+	auto walk = [&](hipStream_t st, int i0, int cnt, int fam) -> int {
+		DWork h = slice(i0);
+		h.fam = fam;
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));   // the bitmap is clear
 		hipLaunchKernelGGL(k_tokenize, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
@@ -1868,6 +1920,23 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const DWork h = slice(i0);
 		DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
 		DWTX_HIP(hipStreamSynchronize(st));
+		bool again = false;   // a one-family walk gave up (k_tokenize): the part is parsed and walked again with both
+		for (int i = i0; i < i0 + cnt; ++i)
+			again = again || host_info[i].hops == WALK_GAVE_UP;
+		if (again) {
+			if (getenv("DWTX_NO_SECOND_WALK")) {   // test hook: shows that a stream takes this path
+				dwtx_set_error("the one-family token walk gave up (DWTX_NO_SECOND_WALK forbids the second)");
+				return DWTX_ERR_DEVICE;
+			}
+			const long items = (long)cnt * FAM * LINK_SHARDS > (long)cnt * 48 * MAX_PLANES ? (long)cnt * FAM * LINK_SHARDS : (long)cnt * 48 * MAX_PLANES;
+			hipLaunchKernelGGL(k_part_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, h, cnt);
+			DWTX_HIP(hipMemsetAsync(h.symbits, 0, sizeof(unsigned) * (size_t)cnt * w.BW, st));
+			int rc2;
+			if ((rc2 = pre(st, i0, cnt, FAM)) || (rc2 = walk(st, i0, cnt, FAM)))
+				return rc2;
+			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+			DWTX_HIP(hipStreamSynchronize(st));
+		}
 		int pmax = 0;
 		for (int i = i0; i < i0 + cnt; ++i)
 			if (!host_info[i].status && host_info[i].pmax > pmax)
@@ -1891,8 +1960,11 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		return DWTX_OK;
 	};
 	int rc;
+	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
+	// (a test hook: it is the path a walk that gave up falls back to).
+	const int fam0 = getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
 	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
-		if ((rc = pre(s, 0, n)) || (rc = walk(s, 0, n)) || (rc = post(s, 0, n)))
+		if ((rc = pre(s, 0, n, fam0)) || (rc = walk(s, 0, n, fam0)) || (rc = post(s, 0, n)))
 			return rc;
 		return done ? done(user, 0, n, part_mask[0]) : DWTX_OK;
 	}
@@ -1900,11 +1972,11 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	// on two streams, the second one half a pipeline behind, so that each half's walk overlaps the
 	// other half's parallel kernels.
 	const int na = n / 2;
-	if ((rc = pre(s, 0, na)))
+	if ((rc = pre(s, 0, na, fam0)))
 		return rc;
 	DWTX_HIP(hipEventRecord(ctx->ev[0], s));              // first half's tables done: its walk starts now
 	DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-	if ((rc = walk(s, 0, na)) || (rc = pre(ctx->aux, na, n - na)) || (rc = walk(ctx->aux, na, n - na)))
+	if ((rc = walk(s, 0, na, fam0)) || (rc = pre(ctx->aux, na, n - na, fam0)) || (rc = walk(ctx->aux, na, n - na, fam0)))
 		return rc;
 	if ((rc = post(s, 0, na)) || (done && (rc = done(user, 0, na, part_mask[0]))))   // the first half's follow-up overlaps the second half's walk
 		return rc;

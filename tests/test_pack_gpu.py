@@ -118,3 +118,56 @@ def test_entropy_stage_on_synthetic_coefficient_planes(ctx, case):
     for cap in (len(want) // 3, len(want) - 5):
         cut, _ = ctx.encode_planes(torch.from_numpy(lin).cuda(), W, H, Cn, capacity=cap)
         assert cut[0] == want[:cap]
+
+
+def _parity_locked_planes(W, H, sign, extra):
+    """Coefficient planes whose finest ring is +-1 everywhere: at bit plane 0 every symbol of that ring is a new
+    one with the same sign, i.e. thousands of 2-bit tokens at VLI order 0 in a row.  All tokens of such a stretch
+    have even length, so a speculative parse that starts an odd number of bits off never meets the real one.
+    `extra` sprinkles `extra` larger coefficients over the coarser rings: it moves the stretch by some bits."""
+    import dwt_amd
+
+    levels, lengths, pixels, _, _ = dwt_amd.compute_lengths(W, H)
+    lin = np.zeros((1, W * H), dtype=np.int32)
+    lin[0, pixels[levels - 1]:pixels[levels]] = sign
+    rng = np.random.default_rng(extra)
+    where = rng.integers(pixels[0], pixels[levels - 1], extra)
+    lin[0, where] = rng.integers(2, 40, extra) * rng.choice([-1, 1], extra)
+    lin[0, :pixels[0]] = rng.integers(-100, 100, pixels[0])
+    return lin
+
+
+@pytest.mark.parametrize("sign", [1, -1])
+def test_streams_the_single_path_family_cannot_follow(ctx, sign, monkeypatch):
+    """The decoder records ONE family of speculative paths per chunk and falls back to two (even and odd start) when
+    its token walk gives up; a ring of equal +-1 coefficients locks the parity for ~100 000 tokens.  Either way the
+    planes must come back exactly, and at least one of the variants must really have taken the second walk."""
+    import torch
+    import dwt_amd
+
+    W = H = 512
+    variants = [_parity_locked_planes(W, H, sign, extra) for extra in (0, 1, 2, 3, 5, 8)]
+    streams = []
+    for lin in variants:
+        want, _ = orc.encode_lin(lin, W, H)
+        got, _ = ctx.encode_planes(torch.from_numpy(lin).cuda(), W, H, 1)
+        assert got[0] == want
+        streams.append(want)
+    for lin, s in zip(variants, streams):
+        back, infos = ctx.decode_planes([s], W, H, 1)
+        assert infos[0].status == 0 and not infos[0].truncated
+        assert (back.cpu().numpy() == lin).all()
+    back, infos = ctx.decode_planes(streams, W, H, 1)   # as one batch (parts of it walk again, others do not)
+    assert (back.cpu().numpy() == np.concatenate(variants)).all()
+    monkeypatch.setenv("DWTX_NO_SECOND_WALK", "1")
+    gave_up = 0
+    for s in streams:
+        try:
+            ctx.decode_planes([s], W, H, 1)
+        except dwt_amd.DwtxError:
+            gave_up += 1
+    assert 0 < gave_up
+    monkeypatch.delenv("DWTX_NO_SECOND_WALK")
+    monkeypatch.setenv("DWTX_TWO_FAMILIES", "1")   # both families from the start: the path the fallback takes
+    back, infos = ctx.decode_planes(streams, W, H, 1)
+    assert (back.cpu().numpy() == np.concatenate(variants)).all()

@@ -76,3 +76,23 @@ def test_bad_headers(ctx):
     data, _ = orc.encode(orc.synth(64, 64, 1, 1, 0))
     _, infos = ctx.decode_planes([b"X" + data[1:], data[:5], data[:6], data], 64, 64, 1)
     assert [i.status for i in infos] == [1, 1, 1, 0]
+
+
+@pytest.mark.parametrize("shape", [(53, 37, 3), (255, 257, 1), (360, 640, 3)])
+def test_both_path_families_from_the_start(ctx, shape, monkeypatch):
+    """The decoder normally records one family of speculative paths and only falls back to two (even / odd start,
+    unpack.hip k_spec) when its token walk gives up.  DWTX_TWO_FAMILIES starts with both: whole streams, prefixes
+    and damaged streams must decode exactly as with one."""
+    from test_oracle import corrupted_blobs
+
+    monkeypatch.setenv("DWTX_TWO_FAMILIES", "1")
+    H, W, Cn = shape
+    data, _ = orc.encode(orc.synth(W, H, Cn, 31, 0))
+    step = max(1, len(data) // 150)
+    check(ctx, [data] + [data[:k] for k in range(1, len(data), step)], W, H, Cn)
+    blobs = []
+    for blob in corrupted_blobs(data, 24, 11):   # plane counts above 16 only damage can produce: refused by design (DESIGN.md section 7)
+        ref = orc.decode_stage(blob, W, H, Cn, -1)
+        if ref is None or max(ref[3]) <= 16:
+            blobs.append(blob)
+    check(ctx, blobs, W, H, Cn)
