@@ -940,6 +940,79 @@ __global__ __launch_bounds__(256) void k_part_reset(DWork h, int cnt)
 		reinterpret_cast<int *>(h.info)[t] = 0;
 }
 
+// decode.c:142-159 header, decode.c:119-134 root image (channel c's coefficients go to root + c * root_stride if
+// root is given), decode.c:183-186 plane counts.  false: unreadable (decode.c exits 1), or more planes than this
+// decoder handles.
+__device__ bool read_preamble(BitReader &br, const UnpackGeom &g, const unsigned char *s8, unsigned long long len, long stream_stride,
+	int &order, int (&planes)[3], int *root, long root_stride)
+{
+	if (len < 6 || s8[0] != 'W' || s8[1] != (g.C == 3 ? '6' : '5') ||
+		(s8[2] | (s8[3] << 8)) + 1 != g.W || (s8[4] | (s8[5] << 8)) + 1 != g.H)
+		return false;
+	br.w = (const unsigned long long *)s8;
+	br.n64 = stream_stride >> 3;
+	br.end_bits = len * 8;
+	br.seek(48);
+	order = 0;
+	for (int c = 0; c < g.C; ++c) {
+		unsigned cnt;
+		if (!br.vli(order, cnt))
+			return false;
+		if (cnt)
+			for (int i = 0; i < g.pixels[0]; ++i) {
+				unsigned v, neg = 0;
+				if (cnt > 32 || !br.read((int)cnt, v))
+					return false;
+				if (v && !br.read(1, neg))
+					return false;
+				if (root)
+					root[c * root_stride + i] = neg ? -(int)v : (int)v;
+			}
+	}
+	for (int c = 0; c < g.C; ++c) {
+		unsigned p;
+		if (!br.vli(order, p) || p > MAX_PLANES)
+			return false;
+		planes[c] = (int)p;
+	}
+	return true;
+}
+
+// How much of its symbol bitmap an image can use follows from its plane counts: every segment owns ceil32(ring
+// size) symbols, a (channel, level) has as many segments as the channel has planes (plus the flat image's
+// "plane -1" segment on level 0).  Clearing only that much — 8-bit pictures have 8 to 11 planes of the 16 the
+// bitmap is laid out for — takes 40 % off the one big clear of the decoder.
+__global__ __launch_bounds__(64) void k_peek(UnpackGeom g, const unsigned char *streams, long stream_stride, const unsigned long long *lens,
+	long BW, unsigned *clear_words, int n)
+{
+	const int img = blockIdx.x * blockDim.x + threadIdx.x;
+	if (img >= n)
+		return;
+	const unsigned char *s8 = streams + img * stream_stride;
+	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
+	BitReader br;
+	int order, planes[3] = { 0, 0, 0 };
+	unsigned long long words = 0;
+	if (read_preamble(br, g, s8, len, stream_stride, order, planes, nullptr, 0)) {
+		unsigned long long per = 0;
+		for (int l = 0; l < g.levels; ++l)
+			per += ((unsigned long long)(g.pixels[l + 1] - g.pixels[l]) + 31) & ~31ull;
+		unsigned long long sym = ((unsigned long long)(g.pixels[1] - g.pixels[0]) + 31) & ~31ull;
+		for (int c = 0; c < g.C; ++c)
+			sym += (unsigned long long)planes[c] * per;
+		words = ((sym >> 4) + 128 + 3) & ~3ull;   // the same slack as BW has
+	}
+	clear_words[img] = (unsigned)(words < (unsigned long long)BW ? words : (unsigned long long)BW);
+}
+
+__global__ __launch_bounds__(256) void k_clear_bitmaps(unsigned *bits, long BW, const unsigned *clear_words)
+{
+	uint4 *dst = reinterpret_cast<uint4 *>(bits + (long)blockIdx.y * BW);
+	const unsigned quads = clear_words[blockIdx.y] >> 2;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += gridDim.x * blockDim.x)
+		dst[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // --------------------------------------------------------------- k_tokenize ---
 
 constexpr unsigned WALK_GAVE_UP = 0xffffffffu;   // DecInfo::hops of an image whose one-family walk was abandoned
@@ -967,41 +1040,15 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	const unsigned char *s8 = streams + img * stream_stride;
 	// a length beyond the stride cannot be real data: only the bytes inside the stride are read
 	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
-	// decode.c:142-159 header
-	if (len < 6 || s8[0] != 'W' || s8[1] != (g.C == 3 ? '6' : '5') ||
-		(s8[2] | (s8[3] << 8)) + 1 != g.W || (s8[4] | (s8[5] << 8)) + 1 != g.H)
-		return;
 	BitReader br;
-	br.w = (const unsigned long long *)s8;
-	br.n64 = stream_stride >> 3;
-	br.end_bits = len * 8;
-	br.seek(48);
 	int order = 0;   // vli.h:24
-	// decode.c:119-134 root image
-	for (int c = 0; c < g.C; ++c) {
-		unsigned cnt;
-		if (!br.vli(order, cnt))
-			return;
-		int *dst = lin + (long)(img * g.C + c) * g.lin_stride;
-		if (cnt)
-			for (int i = 0; i < g.pixels[0]; ++i) {
-				unsigned v, neg = 0;
-				if (cnt > 32 || !br.read((int)cnt, v))
-					return;
-				if (v && !br.read(1, neg))
-					return;
-				dst[i] = neg ? -(int)v : (int)v;
-			}
-	}
 	int planes[3] = { 0, 0, 0 };
+	if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
+		return;
 	int pmax = 0;
-	for (int c = 0; c < g.C; ++c) {   // decode.c:183-186
-		unsigned p;
-		if (!br.vli(order, p) || p > MAX_PLANES)
-			return;
-		planes[c] = (int)p;
-		I.planes[c] = (int)p;
-		pmax = (int)p > pmax ? (int)p : pmax;
+	for (int c = 0; c < g.C; ++c) {
+		I.planes[c] = planes[c];
+		pmax = planes[c] > pmax ? planes[c] : pmax;
 	}
 	I.pmax = pmax;
 	I.status = 0;
@@ -1731,6 +1778,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	const int nplanes = n * C;
 
 	DWork w;
+	unsigned *clear_words = nullptr;   // [n] bitmap words each image can use (k_peek)
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
 #ifdef DWTX_DEBUG_HOOKS   // tools/dbg_walker.py: device address for the walker's cycle counters (never in the shipped build)
@@ -1796,6 +1844,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const size_t o_tc = take(sizeof(unsigned) * (LINK_ROUNDS + 2) * (size_t)n * FAM * LINK_SHARDS);
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
 		const size_t o_nc = take(sizeof(int) * (size_t)n);
+		const size_t o_cw = take(sizeof(unsigned) * (size_t)n);
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
 		if (!chunks)
 			return DWTX_ERR_NOMEM;
@@ -1821,6 +1870,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		DWTX_HIP(hipMemsetAsync(w.todo_count, 0, sizeof(unsigned) * (LINK_ROUNDS + 2) * (size_t)w.todo_round, ctx->stream));
 		w.nhops = (int *)(chunks + o_nh);
 		w.nch = (int *)(chunks + o_nc);
+		clear_words = (unsigned *)(chunks + o_cw);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		// The symbol bitmap (the one big clear, ~64 MB per 4096x4096 plane) is only needed by the token walk:
@@ -1833,7 +1883,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		}
 		DWTX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));            // earlier work on the main stream may still read the bitmap
 		DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[2], 0));
-		DWTX_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (size_t)n * w.BW, ctx->aux));
+		hipLaunchKernelGGL(k_peek, dim3(dwtx_cdiv(n, 64)), dim3(64), 0, ctx->aux, g, streams, (long)stream_stride, dev_lens, w.BW, clear_words, n);
+		hipLaunchKernelGGL(k_clear_bitmaps, dim3(64, n), dim3(256), 0, ctx->aux, bits, w.BW, clear_words);
 		DWTX_HIP(hipEventRecord(ctx->ev[3], ctx->aux));
 	}
 	hipStream_t s = ctx->stream;
