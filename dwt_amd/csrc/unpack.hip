@@ -1885,13 +1885,15 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[2], 0));
 		hipLaunchKernelGGL(k_peek, dim3(dwtx_cdiv(n, 64)), dim3(64), 0, ctx->aux, g, streams, (long)stream_stride, dev_lens, w.BW, clear_words, n);
 		hipLaunchKernelGGL(k_clear_bitmaps, dim3(64, n), dim3(256), 0, ctx->aux, bits, w.BW, clear_words);
+		// (the per-tile counters are first used after the token walk too: beside the clear, on the main stream, this
+		// trivial kernel waited 0.5 ms for a free slot and held the chunk kernels up)
+		hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, ctx->aux, g, w, nplanes);
 		DWTX_HIP(hipEventRecord(ctx->ev[3], ctx->aux));
 	}
 	hipStream_t s = ctx->stream;
 	// decode.c:177-179 zeroes everything; here the rings are written exactly once by k_apply_all, so only
 	// the root image (written by the token walker when it has any bits) needs clearing
 	DWTX_HIP(hipMemset2DAsync(lin, sizeof(int) * (size_t)g.lin_stride, 0, sizeof(int) * (size_t)g.pixels[0], nplanes, s));
-	hipLaunchKernelGGL(k_tiles_init, dim3(dwtx_cdiv(NT, 256), nplanes), dim3(256), 0, s, g, w, nplanes);
 	hipLaunchKernelGGL(k_nch, dim3(dwtx_cdiv(n, 256)), dim3(256), 0, s, w, dev_lens, n);
 
 	// everything below works on a range of images [i0, i0+cnt): all tables are per image
