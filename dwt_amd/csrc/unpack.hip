@@ -2015,7 +2015,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	int rc;
 	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
 	// (a test hook: it is the path a walk that gave up falls back to).
-	const int fam0 = getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
+	// One or two images leave most of the chip idle anyway: both families then, for the shorter walk.
+	const int fam0 = n <= 2 || getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
 	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
 		if ((rc = pre(s, 0, n, fam0)) || (rc = walk(s, 0, n, fam0)) || (rc = post(s, 0, n)))
 			return rc;
