@@ -10,7 +10,7 @@ raise.
 import ctypes as C
 
 from . import _lib
-from ._lib import Geom, Stats, StreamInfo, DecodeInfo, LIB_PATH  # noqa: F401
+from ._lib import Geom, Stats, StreamInfo, DecodeInfo, Index, SegIndex, INDEX_MAGIC, INDEX_MAX_SEGS, LIB_PATH  # noqa: F401
 
 __all__ = ["Context", "DwtxError", "compute_lengths", "geometry", "Geom", "Stats"]
 
@@ -72,6 +72,16 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_index(self, offered=None, wanted=0):
+        """Sidecar indices for the decode calls that follow (dwtx_ctx_set_index): `offered` is an array of Index
+        made by new_indices()/an earlier decode (entry i goes with image i of a call), `wanted` the number of
+        entries to collect.  Returns the array that will receive them (or None).  set_index() ends it."""
+        out = (Index * wanted)() if wanted else None
+        self._index = (offered, out)   # the library keeps the pointers
+        _check(self.lib.dwtx_ctx_set_index(self.h, C.cast(offered, C.c_void_p) if offered is not None else None,
+                                           C.cast(out, C.c_void_p) if out is not None else None), "dwtx_ctx_set_index")
+        return out
 
     def sync(self):
         _check(self.lib.dwtx_sync(self.h), "dwtx_sync")

@@ -40,6 +40,21 @@ class DecodeInfo(C.Structure):
     ]
 
 
+class SegIndex(C.Structure):
+    _fields_ = [("bit", C.c_ulonglong), ("sym_base", C.c_ulonglong), ("n1", C.c_uint), ("cnt", C.c_uint),
+                ("desc", C.c_uint), ("order", C.c_uint)]
+
+
+INDEX_MAGIC = 0x49545744
+INDEX_MAX_SEGS = 768
+
+
+class Index(C.Structure):
+    """dwtx_index: the sidecar index of one stream (include/dwtx.h)."""
+    _fields_ = [("magic", C.c_uint), ("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("nsegs", C.c_int),
+                ("reserved", C.c_int), ("stream_bits", C.c_ulonglong), ("seg", SegIndex * INDEX_MAX_SEGS)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("meta_bits", C.c_int),
@@ -59,6 +74,7 @@ SYMBOLS = {
     "dwtx_ctx_destroy": (None, [_vp]),
     "dwtx_last_error": (C.c_char_p, []),
     "dwtx_sync": (_i, [_vp]),
+    "dwtx_ctx_set_index": (_i, [_vp, _vp, _vp]),
     "dwtx_stream": (_vp, [_vp]),
     "dwtx_malloc": (_vp, [_vp, _sz]),
     "dwtx_free": (None, [_vp, _vp]),

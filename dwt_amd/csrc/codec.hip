@@ -331,8 +331,10 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 			e = hipStreamWaitEvent(ms, ev_out[slot], 0);   // part k-2's pixels have left this buffer
 		if (e != hipSuccess)
 			break;
+		ctx->index_base = (size_t)i0;   // sidecar index entries follow the images (dwtx_ctx_set_index)
 		const int r = dwtx_decode_device(ctx, dstr + stream_stride * (size_t)slot * P, stream_stride, dlens + (size_t)slot * P, W, H, C, cnt,
 			levels_max, dpix + img_bytes * (size_t)slot * P, img_bytes, info + i0);
+		ctx->index_base = 0;
 		if (r) {
 			rc = r;
 			break;

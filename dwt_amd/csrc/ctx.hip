@@ -62,6 +62,16 @@ extern "C" int dwtx_ctx_create_on_stream(int device, void *stream, dwtx_ctx **ou
 	return ctx_create(device, stream, false, out);
 }
 
+extern "C" int dwtx_ctx_set_index(dwtx_ctx *c, const dwtx_index *in, dwtx_index *out)
+{
+	if (!c)
+		return DWTX_ERR_ARG;
+	c->index_in = in;
+	c->index_out = out;
+	c->index_base = 0;
+	return DWTX_OK;
+}
+
 extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 {
 	if (!c)

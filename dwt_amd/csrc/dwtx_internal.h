@@ -23,6 +23,9 @@ struct dwtx_ctx {
 	hipStream_t copy;      // host-buffer wrappers: transfers of one part of a batch overlap the kernels of another (codec.hip)
 	hipEvent_t cev[6];
 	bool have_copy;
+	const dwtx_index *index_in;   // dwtx_ctx_set_index: sidecar indices offered to / asked from the decode calls
+	dwtx_index *index_out;
+	size_t index_base;            // entry of the current call's first image (the host pipeline decodes a batch in parts)
 };
 
 void dwtx_free_plans(dwtx_ctx *ctx);

@@ -40,6 +40,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 namespace {
 
@@ -80,6 +81,27 @@ struct DecInfo {
 	unsigned zeros_left;               // the run-length reader's counter at the end (rle.h:43-46 reports it when > 1)
 };
 
+// The sidecar index (never part of the .dwt): the token walk's state where each segment's
+// first pass begins.  With it every segment can be walked by a wave of its own (k_tokenize<true>), and because a
+// segment walked from entry k's state must arrive exactly in entry k+1's, the index is checked for free
+// (k_segjoin): a wrong or foreign index only costs the fallback to the serial walk.
+struct SegIndex {
+	unsigned long long bit;       // stream position of the segment's first pass
+	unsigned long long sym_base;  // first symbol slot of the segment in the image's bitmap
+	unsigned n1;                  // symbols of the first pass (coefficients still insignificant)
+	unsigned cnt;                 // rle.h:25 zero-run counter on entry
+	unsigned desc;                // c | l << 4 | (p + 1) << 8
+	unsigned order;               // vli.h:24 order on entry
+};
+
+struct SegResult {
+	unsigned long long bit;       // position after the segment (first pass and refinement block)
+	unsigned order, cnt, ones;
+	unsigned nhops, hopped, walked;
+	unsigned ok;                  // 1: walked to its end without a stop condition
+	unsigned pad;
+};
+
 struct DWork {
 	DecInfo *info;                  // [n]
 	int *seg_desc;                  // [n][MAX_SEGS]
@@ -116,6 +138,10 @@ struct DWork {
 	int *nch;                       // [n] chunks that hold stream bytes (rounded so that nch+1 is a multiple of 4), <= NCH
 	long NCH, NB;
 	long MAX_HOPS;
+	SegIndex *idx;                  // [n][MAX_SEGS] state at the start of every segment: written by the serial walk, read by the indexed one
+	SegResult *segres;              // [n][MAX_SEGS] indexed walk: where each segment's own wave ended up
+	int *idx_nsegs;                 // [n] segments in idx (indexed walk: 0 = no usable index for this image)
+	unsigned *seg_slot;             // [n][MAX_SEGS + 1] indexed walk: first hop record of every segment's private stretch
 	int fam;                        // families in use this pass: 1 (the usual case) or FAM (see k_spec); the tables keep FAM rows per image either way
 };
 
@@ -1015,17 +1041,61 @@ __global__ __launch_bounds__(256) void k_clear_bitmaps(unsigned *bits, long BW, 
 
 // --------------------------------------------------------------- k_tokenize ---
 
+// decode.c:198-243: the order in which (channel, level, plane) segments follow one another.  seg(c, l, p) decodes
+// one and says whether decoding goes on; `level` and `missing` are kept as decode.c:197,203,219,236 keeps them.
+// Returns whether the walk stopped before the schedule's end (decode.c:199-200,204,221,238).
+template <class F>
+__device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&planes)[3], int pmax, int &level, int *missing, F &&seg)
+{
+	const int levels = g.levels;
+	const int layers_max = 2 * (levels > pmax ? levels : pmax) - 1;
+	bool stop = g.levels_max == 0;        // decode.c:199-200
+	if (!stop && pmax == planes[0]) {     // decode.c:201-207
+		level = 0;
+		if (seg(0, 0, planes[0] - 1))
+			--missing[0];
+		else
+			stop = true;
+	}
+	for (int layer = 0; !stop && layer < layers_max; ++layer) {   // decode.c:208-243
+		for (int l = 0; !stop && l < levels && l <= layer + 1; ++l) {
+			if (l >= g.levels_max) {
+				stop = true;
+				break;
+			}
+			const int p = pmax - 1 - (layer + 1 - l);
+			if (p < 0 || p >= planes[0])
+				continue;
+			level = level < l ? l : level;
+			if (seg(0, l, p))
+				--missing[l];
+			else
+				stop = true;
+		}
+		for (int l = 0; !stop && l < levels && l <= layer; ++l) {
+			if (l >= g.levels_max) {
+				stop = true;
+				break;
+			}
+			const int p = pmax - 1 - (layer - l);
+			for (int c = 1; !stop && c < g.C; ++c) {
+				if (p < 0 || p >= planes[c])
+					continue;
+				level = level < l ? l : level;
+				if (seg(c, l, p))
+					--missing[c * 16 + l];
+				else
+					stop = true;
+			}
+		}
+	}
+	return stop;
+}
+
 constexpr unsigned WALK_GAVE_UP = 0xffffffffu;   // DecInfo::hops of an image whose one-family walk was abandoned
 
-__global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
-	const unsigned long long *lens, int *lin, int n)
+__device__ __forceinline__ void info_begin(DecInfo &I, const UnpackGeom &g)
 {
-	const int img = blockIdx.x;
-	if (img >= n)
-		return;
-	// All 64 lanes walk in step on uniform values (the compiler keeps them on the scalar unit), so that
-	// chunk_scan can use the lanes; plain stores just repeat the same value, atomics are lane 0's.
-	DecInfo &I = w.info[img];
 	I.status = 1;
 	I.W = g.W;
 	I.H = g.H;
@@ -1037,30 +1107,60 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.pmax = 0;
 	for (int i = 0; i < 48; ++i)
 		I.missing[i] = 0;
+}
+
+// SEG = false: one wave per image walks the whole stream (grid: images).
+// SEG = true: one wave per segment (grid: MAX_SEGS x images) starts from the state the sidecar index gives for it;
+// k_segjoin afterwards checks that the segments fit together and puts their hop records in a row.
+template <bool SEG>
+__global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
+	const unsigned long long *lens, int *lin, int n)
+{
+	const int img = SEG ? blockIdx.y : blockIdx.x;
+	if (img >= n)
+		return;
+	const int seg_k = SEG ? (int)blockIdx.x : 0;
+	if (SEG && seg_k >= w.idx_nsegs[img])
+		return;
+	// All 64 lanes walk in step on uniform values (the compiler keeps them on the scalar unit), so that
+	// chunk_scan can use the lanes; plain stores just repeat the same value, atomics are lane 0's.
+	DecInfo &I = w.info[img];
 	const unsigned char *s8 = streams + img * stream_stride;
 	// a length beyond the stride cannot be real data: only the bytes inside the stride are read
 	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
 	BitReader br;
 	int order = 0;   // vli.h:24
 	int planes[3] = { 0, 0, 0 };
-	if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
-		return;
 	int pmax = 0;
-	for (int c = 0; c < g.C; ++c) {
-		I.planes[c] = planes[c];
-		pmax = planes[c] > pmax ? planes[c] : pmax;
-	}
-	I.pmax = pmax;
-	I.status = 0;
-	const int levels = g.levels;
-	for (int c = 0; c < g.C; ++c)
-		for (int l = 0; l < levels; ++l)
-			I.missing[c * 16 + l] = planes[c];
-
+	int nonsig_own[1] = { 0 };   // SEG: the one counter this segment needs
 	int *nonsig = w.nonsig + (long)img * 48;
-	for (int c = 0; c < g.C; ++c)
-		for (int l = 0; l < levels; ++l)
-			nonsig[c * 16 + l] = g.pixels[l + 1] - g.pixels[l];
+	SegIndex *idx = w.idx + (long)img * MAX_SEGS;
+	if (!SEG) {
+		info_begin(I, g);
+		if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
+			return;
+		for (int c = 0; c < g.C; ++c) {
+			I.planes[c] = planes[c];
+			pmax = planes[c] > pmax ? planes[c] : pmax;
+		}
+		I.pmax = pmax;
+		I.status = 0;
+		for (int c = 0; c < g.C; ++c)
+			for (int l = 0; l < g.levels; ++l)
+				I.missing[c * 16 + l] = planes[c];
+		for (int c = 0; c < g.C; ++c)
+			for (int l = 0; l < g.levels; ++l)
+				nonsig[c * 16 + l] = g.pixels[l + 1] - g.pixels[l];
+	} else {
+		br.w = (const unsigned long long *)s8;
+		br.n64 = stream_stride >> 3;
+		br.end_bits = len * 8;
+		br.b = idx[seg_k].bit < br.end_bits ? idx[seg_k].bit : br.end_bits;
+		br.base = 0;
+		br.f0 = br.f1 = br.f2 = br.f3 = br.f4 = br.f5 = 0;
+		order = (int)(idx[seg_k].order & 31u);
+		nonsig_own[0] = (int)idx[seg_k].n1;
+	}
 	int *sd = w.seg_desc + (long)img * MAX_SEGS;
 	unsigned long long *ssym = w.seg_symbase + (long)img * MAX_SEGS;
 	unsigned long long *sb2 = w.seg_b2 + (long)img * MAX_SEGS;
@@ -1073,9 +1173,9 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	bm.lead = threadIdx.x == 0;
 	const int wl = (int)threadIdx.x;   // lane, for the few places where the lanes share work
 
-	unsigned cnt = 0;              // rle.h:25
-	unsigned long long symtotal = 0;
-	int nsegs = 0, level = -1;
+	unsigned cnt = SEG ? idx[seg_k].cnt : 0u;              // rle.h:25
+	unsigned long long symtotal = SEG ? idx[seg_k].sym_base : 0ull;
+	int nsegs = seg_k, level = -1;
 
 	// stitched-chunk tables of this stream (k_spec / k_link / k_scan_* / k_breaks)
 	const unsigned short *exitX0 = w.exitX + (long)img * FAM * w.NCH;
@@ -1100,20 +1200,33 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	long checked = -1;
 	int nhops = 0;
 	unsigned hopped = 0, walked = 0;
-	bool br_synced = true;   // br's look-ahead registers match br.b
+	bool br_synced = !SEG;   // br's look-ahead registers match br.b
 	bool eof = false;        // a read ran past the end of the data (the reference prints bytes.h:101 once)
-	int *hop_seg = w.hop_seg + (long)img * w.MAX_HOPS;
-	unsigned *hop_first = w.hop_first + (long)img * w.MAX_HOPS, *hop_last = w.hop_last + (long)img * w.MAX_HOPS,
-		*hop_q0 = w.hop_q0 + (long)img * w.MAX_HOPS, *hop_entry = w.hop_entry + (long)img * w.MAX_HOPS,
-		*hop_ntok = w.hop_ntok + (long)img * w.MAX_HOPS;
+	// SEG: the segment's records go to a stretch of the image's list that is its own (k_segprep sized it)
+	const long hop0 = (long)img * w.MAX_HOPS + (SEG ? (long)w.seg_slot[(long)img * (MAX_SEGS + 1) + seg_k] : 0l);
+	const long hop_cap = SEG ? (long)(w.seg_slot[(long)img * (MAX_SEGS + 1) + seg_k + 1] - w.seg_slot[(long)img * (MAX_SEGS + 1) + seg_k]) : w.MAX_HOPS;
+	int *hop_seg = w.hop_seg + hop0;
+	unsigned *hop_first = w.hop_first + hop0, *hop_last = w.hop_last + hop0, *hop_q0 = w.hop_q0 + hop0, *hop_entry = w.hop_entry + hop0,
+		*hop_ntok = w.hop_ntok + hop0;
 
 	// decode.c:67-100 without touching coefficients; false = stop decoding (decode.c:204,221,238)
 	auto segment = [&](int c, int l, int p) -> bool {
 		const int num = g.pixels[l + 1] - g.pixels[l];
-		const int n1 = p < 0 ? num : nonsig[c * 16 + l];
+		int &left = SEG ? nonsig_own[0] : nonsig[c * 16 + l];   // coefficients of this (channel, level) still insignificant
+		const int n1 = p < 0 ? num : left;
 		const int n2 = num - n1;
 		const int k = nsegs++;
 		const unsigned long long sym0 = symtotal;
+		if (!SEG) {   // what a wave of its own would have to know to start here (the sidecar index)
+			SegIndex e;
+			e.bit = br.b;
+			e.sym_base = sym0;
+			e.n1 = (unsigned)n1;
+			e.cnt = cnt;
+			e.desc = (unsigned)(c | (l << 4) | ((p + 1) << 8));
+			e.order = (unsigned)order;
+			idx[k] = e;
+		}
 		symtotal += ((unsigned long long)num + 31) & ~31ull;
 		sd[k] = c | (l << 4) | ((p + 1) << 8);
 		ssym[k] = sym0;
@@ -1128,7 +1241,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			unsigned zr;
 			if (cnt == 0) {   // rle.h:70-75: a token starts here
 				const long ci = (long)(br.b >> CH_LOG2);
-				if (ci >= 1 && ci <= lastsafe && nhops < w.MAX_HOPS) {
+				if (ci >= 1 && ci <= lastsafe && nhops < hop_cap) {
 					const unsigned need = (unsigned)(n1 - q);
 					const int rel = (int)(br.b - ((unsigned long long)ci << CH_LOG2));
 					bool moved = false;
@@ -1264,7 +1377,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 			++q;
 		}
 		if (p >= 0)
-			nonsig[c * 16 + l] = n1 - ones;
+			left = n1 - ones;
 		if (!ok)
 			return false;
 		if (p >= 0 && n2 > 0) {
@@ -1290,47 +1403,28 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		return true;
 	};
 
-	const int layers_max = 2 * (levels > pmax ? levels : pmax) - 1;
-	bool stop = g.levels_max == 0;        // decode.c:199-200
-	if (!stop && pmax == planes[0]) {     // decode.c:201-207
-		level = 0;
-		if (segment(0, 0, planes[0] - 1))
-			--I.missing[0];
-		else
-			stop = true;
+	bool stop = false;
+	if (SEG) {
+		const unsigned d = idx[seg_k].desc;
+		const int c = (int)(d & 15u), l = (int)((d >> 4) & 15u), p = (int)(d >> 8) - 1;
+		const bool sane = c < g.C && l < g.levels && p < MAX_PLANES && (unsigned long long)idx[seg_k].n1 <= (unsigned long long)(g.pixels[l + 1] - g.pixels[l]) &&
+			idx[seg_k].sym_base + (unsigned long long)(g.pixels[l + 1] - g.pixels[l]) + 32ull <= (unsigned long long)w.BW * 16ull;
+		const bool went = sane && segment(c, l, p);
+		bm.flush();
+		SegResult r;
+		r.bit = br.b;
+		r.order = (unsigned)order;
+		r.cnt = cnt;
+		r.ones = sane ? idx[seg_k].n1 - (unsigned)nonsig_own[0] : 0u;
+		r.nhops = (unsigned)nhops;
+		r.hopped = hopped;
+		r.walked = walked;
+		r.ok = went && !giveup && !eof ? 1u : 0u;
+		r.pad = 0u;
+		w.segres[(long)img * MAX_SEGS + seg_k] = r;
+		return;
 	}
-	for (int layer = 0; !stop && layer < layers_max; ++layer) {   // decode.c:208-243
-		for (int l = 0; !stop && l < levels && l <= layer + 1; ++l) {
-			if (l >= g.levels_max) {
-				stop = true;
-				break;
-			}
-			const int p = pmax - 1 - (layer + 1 - l);
-			if (p < 0 || p >= planes[0])
-				continue;
-			level = level < l ? l : level;
-			if (segment(0, l, p))
-				--I.missing[l];
-			else
-				stop = true;
-		}
-		for (int l = 0; !stop && l < levels && l <= layer; ++l) {
-			if (l >= g.levels_max) {
-				stop = true;
-				break;
-			}
-			const int p = pmax - 1 - (layer - l);
-			for (int c = 1; !stop && c < g.C; ++c) {
-				if (p < 0 || p >= planes[c])
-					continue;
-				level = level < l ? l : level;
-				if (segment(c, l, p))
-					--I.missing[c * 16 + l];
-				else
-					stop = true;
-			}
-		}
-	}
+	stop = walk_schedule(g, planes, pmax, level, I.missing, segment);
 	bm.flush();
 	if (giveup) {   // nothing of this walk is used: no records for k_hopbits, the marker for the host
 		w.nhops[img] = 0;
@@ -1349,6 +1443,144 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.nsegs = nsegs;
 	I.truncated = stop ? (eof ? 3 : 1) : 0;
 	I.bits_used = br.b;
+}
+
+// ------------------------------------------------------- indexed walk: before / after ---
+// k_segprep (one thread per image): every segment's private stretch of hop records, 8 + one per eight chunks
+// between its start and the next segment's (the serial walk's MAX_HOPS is the sum of exactly these).  An index
+// whose positions are not ascending inside the stream is dropped here (idx_nsegs = 0: the host walks serially).
+__global__ __launch_bounds__(64) void k_segprep(DWork w, const unsigned long long *lens, long stream_stride, int n)
+{
+	const int img = blockIdx.x * blockDim.x + threadIdx.x;
+	if (img >= n)
+		return;
+	const int K = w.idx_nsegs[img];
+	const SegIndex *idx = w.idx + (long)img * MAX_SEGS;
+	unsigned *slot = w.seg_slot + (long)img * (MAX_SEGS + 1);
+	const unsigned long long end_bits = 8ull * (lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride);
+	bool good = K > 0 && K <= MAX_SEGS;
+	unsigned long long at = 0;
+	for (int k = 0; good && k < K; ++k) {
+		const unsigned long long b = idx[k].bit, nb = k + 1 < K ? idx[k + 1].bit : end_bits;
+		good = b <= nb && nb <= end_bits;
+		slot[k] = (unsigned)at;
+		at += 8ull + ((nb - b) >> (CH_LOG2 + 3));
+	}
+	slot[K > 0 && K <= MAX_SEGS ? K : 0] = (unsigned)at;
+	if (!good || at > (unsigned long long)w.MAX_HOPS)
+		w.idx_nsegs[img] = 0;
+}
+
+// k_segjoin (one wave per image, uniform code): the serial walk's bookkeeping around the segments that
+// k_tokenize<true> walked on their own.  It reads the preamble, replays the schedule and checks every link of the
+// chain — segment k must be the schedule's k-th segment, start where segment k-1 arrived (position, VLI order, run
+// counter), hold the symbols the counters of its (channel, level) say and own the next symbol slots — so an index
+// that passes describes exactly the walk the serial kernel would have made.  Then the segments' hop records move
+// together into one ascending list.  Anything else: the give-up marker, and the host walks the part serially.
+__global__ __launch_bounds__(64) void k_segjoin(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride,
+	const unsigned long long *lens, int *lin, int n)
+{
+	const int img = blockIdx.x;
+	if (img >= n)
+		return;
+	const int lane = threadIdx.x;
+	DecInfo &I = w.info[img];
+	info_begin(I, g);
+	const unsigned char *s8 = streams + img * stream_stride;
+	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
+	BitReader br;
+	int order = 0, planes[3] = { 0, 0, 0 };
+	if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
+		return;   // unreadable: status 1, as from the serial walk
+	int pmax = 0;
+	for (int c = 0; c < g.C; ++c) {
+		I.planes[c] = planes[c];
+		pmax = planes[c] > pmax ? planes[c] : pmax;
+	}
+	I.pmax = pmax;
+	I.status = 0;
+	for (int c = 0; c < g.C; ++c)
+		for (int l = 0; l < g.levels; ++l)
+			I.missing[c * 16 + l] = planes[c];
+	const int K = w.idx_nsegs[img];
+	const SegIndex *idx = w.idx + (long)img * MAX_SEGS;
+	const SegResult *res = w.segres + (long)img * MAX_SEGS;
+	int nonsig[48];
+	for (int c = 0; c < g.C; ++c)
+		for (int l = 0; l < g.levels; ++l)
+			nonsig[c * 16 + l] = g.pixels[l + 1] - g.pixels[l];
+	unsigned long long at = br.b, symtotal = 0;
+	unsigned cnt = 0, hopped = 0, walked = 0;
+	int k = 0, level = -1;
+	bool good = K > 0 && g.levels_max >= g.levels;
+	const bool stop = walk_schedule(g, planes, pmax, level, I.missing, [&](int c, int l, int p) {
+		const int num = g.pixels[l + 1] - g.pixels[l];
+		const int n1 = p < 0 ? num : nonsig[c * 16 + l];
+		good = good && k < K;
+		if (good) {
+			const SegIndex e = idx[k];
+			const SegResult r = res[k];
+			good = e.desc == (unsigned)(c | (l << 4) | ((p + 1) << 8)) && e.bit == at && e.order == (unsigned)order && e.cnt == cnt &&
+				e.n1 == (unsigned)n1 && e.sym_base == symtotal && r.ok != 0u && r.ones <= (unsigned)n1;
+			if (good) {
+				at = r.bit;
+				order = (int)r.order;
+				cnt = r.cnt;
+				if (p >= 0)
+					nonsig[c * 16 + l] = n1 - (int)r.ones;
+				symtotal += ((unsigned long long)num + 31) & ~31ull;
+				hopped += r.hopped;
+				walked += r.walked;
+				++k;
+			}
+		}
+		return good;
+	});
+	good = good && !stop && k == K;
+	if (!good) {
+		w.nhops[img] = 0;
+		I.hops = WALK_GAVE_UP;
+		return;
+	}
+	// the hop records of all segments in one row (a segment's stretch never starts before the row's end: forward copy)
+	const unsigned *slot = w.seg_slot + (long)img * (MAX_SEGS + 1);
+	const long h0 = (long)img * w.MAX_HOPS;
+	unsigned total = 0;
+	for (int j = 0; j < K; ++j) {
+		const unsigned nh = res[j].nhops, from = slot[j];
+		if (from != total)
+			for (unsigned i0 = 0; i0 < nh; i0 += 64) {
+				const unsigned i = i0 + (unsigned)lane;
+				int a = 0;
+				unsigned b = 0, c2 = 0, d = 0, e = 0, f = 0;
+				if (i < nh) {
+					a = w.hop_seg[h0 + from + i];
+					b = w.hop_first[h0 + from + i];
+					c2 = w.hop_last[h0 + from + i];
+					d = w.hop_q0[h0 + from + i];
+					e = w.hop_entry[h0 + from + i];
+					f = w.hop_ntok[h0 + from + i];
+				}
+				if (i < nh) {
+					w.hop_seg[h0 + total + i] = a;
+					w.hop_first[h0 + total + i] = b;
+					w.hop_last[h0 + total + i] = c2;
+					w.hop_q0[h0 + total + i] = d;
+					w.hop_entry[h0 + total + i] = e;
+					w.hop_ntok[h0 + total + i] = f;
+				}
+			}
+		total += nh;
+	}
+	w.nhops[img] = (int)total;
+	I.hops = total;
+	I.hopped_chunks = hopped;
+	I.walked_tokens = walked;
+	I.zeros_left = cnt;
+	I.level = level;
+	I.nsegs = K;
+	I.truncated = 0;
+	I.bits_used = at;
 }
 
 // ------------------------------------------------------------------ k_rank ---
@@ -1845,6 +2077,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const size_t o_nh = take(sizeof(int) * (size_t)n);
 		const size_t o_nc = take(sizeof(int) * (size_t)n);
 		const size_t o_cw = take(sizeof(unsigned) * (size_t)n);
+		const size_t o_ix = take(sizeof(SegIndex) * (size_t)n * MAX_SEGS);
+		const size_t o_sr = take(sizeof(SegResult) * (size_t)n * MAX_SEGS);
+		const size_t o_in = take(sizeof(int) * (size_t)n);
+		const size_t o_sl = take(sizeof(unsigned) * (size_t)n * (MAX_SEGS + 1));
 		char *chunks = (char *)dwtx_scratch(ctx, SLOT_UP_CHUNKS, off);
 		if (!chunks)
 			return DWTX_ERR_NOMEM;
@@ -1871,6 +2107,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		w.nhops = (int *)(chunks + o_nh);
 		w.nch = (int *)(chunks + o_nc);
 		clear_words = (unsigned *)(chunks + o_cw);
+		w.idx = (SegIndex *)(chunks + o_ix);
+		w.segres = (SegResult *)(chunks + o_sr);
+		w.idx_nsegs = (int *)(chunks + o_in);
+		w.seg_slot = (unsigned *)(chunks + o_sl);
 		DWTX_HIP(hipMemsetAsync(w.nhops, 0, sizeof(int) * (size_t)n, ctx->stream));
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		// The symbol bitmap (the one big clear, ~64 MB per 4096x4096 plane) is only needed by the token walk:
@@ -1930,6 +2170,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		h.todo_count += (size_t)i0 * FAM * LINK_SHARDS;
 		h.nhops += i0;
 		h.nch += i0;
+		h.idx += (size_t)i0 * MAX_SEGS;
+		h.segres += (size_t)i0 * MAX_SEGS;
+		h.idx_nsegs += i0;
+		h.seg_slot += (size_t)i0 * (MAX_SEGS + 1);
 		if (h.dbg)
 			h.dbg += (size_t)i0 * 4;
 		return h;
@@ -1955,12 +2199,48 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
 	};
-	auto walk = [&](hipStream_t st, int i0, int cnt, int fam) -> int {
+	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
+	// (a test hook: it is the path a walk that gave up falls back to).
+	// One or two images leave most of the chip idle anyway: both families then, for the shorter walk.
+	const int fam0 = n <= 2 || getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
+	// Sidecar indices (dwtx_ctx_set_index): a part of the batch whose images all come with a plausible index is
+	// walked segment-parallel; k_segjoin proves the index on the way or hands the part back to the serial walk.
+	const dwtx_index *ix_in = ctx->index_in ? ctx->index_in + ctx->index_base : nullptr;
+	dwtx_index *ix_out = ctx->index_out ? ctx->index_out + ctx->index_base : nullptr;
+	static_assert(sizeof(dwtx_seg_index) == sizeof(SegIndex) && DWTX_INDEX_MAX_SEGS == MAX_SEGS, "SegIndex is the device image of dwtx_seg_index");
+	auto indexed = [&](int i0, int cnt) -> bool {
+		if (!ix_in || g.levels_max < g.levels || getenv("DWTX_NO_INDEX"))
+			return false;
+		for (int i = i0; i < i0 + cnt; ++i)
+			if (ix_in[i].magic != DWTX_INDEX_MAGIC || ix_in[i].W != W || ix_in[i].H != H || ix_in[i].C != C || ix_in[i].nsegs <= 0 ||
+				ix_in[i].nsegs > MAX_SEGS)
+				return false;
+		return true;
+	};
+	bool part_indexed[2] = { false, false };
+	std::vector<int> index_segs(ix_in ? (size_t)n : 0u);
+	auto walk = [&](hipStream_t st, int i0, int cnt, int fam, bool use_index) -> int {
 		DWork h = slice(i0);
 		h.fam = fam;
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));   // the bitmap is clear
-		hipLaunchKernelGGL(k_tokenize, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
+		part_indexed[i0 ? 1 : 0] = use_index;
+		if (use_index) {
+			int maxk = 0;
+			for (int i = 0; i < cnt; ++i) {
+				const int k = ix_in[i0 + i].nsegs;
+				index_segs[(size_t)(i0 + i)] = k;   // (lives as long as this call: the copy below may still be reading it)
+				maxk = k > maxk ? k : maxk;
+				DWTX_HIP(hipMemcpyAsync(h.idx + (size_t)i * MAX_SEGS, ix_in[i0 + i].seg, sizeof(SegIndex) * (size_t)k, hipMemcpyHostToDevice, st));
+			}
+			DWTX_HIP(hipMemcpyAsync(h.idx_nsegs, index_segs.data() + i0, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, st));
+			hipLaunchKernelGGL(k_segprep, dim3(dwtx_cdiv(cnt, 64)), dim3(64), 0, st, h, dev_lens + i0, (long)stream_stride, cnt);
+			hipLaunchKernelGGL(k_tokenize<true>, dim3(maxk, cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
+				lin + (size_t)i0 * C * g.lin_stride, cnt);
+			hipLaunchKernelGGL(k_segjoin, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
+				lin + (size_t)i0 * C * g.lin_stride, cnt);
+		} else
+		hipLaunchKernelGGL(k_tokenize<false>, dim3(cnt), dim3(64), 0, st, g, h, str, (long)stream_stride, dev_lens + i0,
 			lin + (size_t)i0 * C * g.lin_stride, cnt);
 		const unsigned hblocks = (unsigned)((w.NCH + 255) / 256);
 		hipLaunchKernelGGL(k_hopbits, dim3(hblocks < CHUNK_GRID ? hblocks : CHUNK_GRID, cnt), dim3(256), 0, st, h, str, (long)stream_stride);
@@ -1973,23 +2253,56 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const DWork h = slice(i0);
 		DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
 		DWTX_HIP(hipStreamSynchronize(st));
-		bool again = false;   // a one-family walk gave up (k_tokenize): the part is parsed and walked again with both
-		for (int i = i0; i < i0 + cnt; ++i)
-			again = again || host_info[i].hops == WALK_GAVE_UP;
-		if (again) {
-			if (getenv("DWTX_NO_SECOND_WALK")) {   // test hook: shows that a stream takes this path
-				dwtx_set_error("the one-family token walk gave up (DWTX_NO_SECOND_WALK forbids the second)");
-				return DWTX_ERR_DEVICE;
-			}
+		// A walk that did not come through leaves the marker: an indexed walk whose index does not fit the stream is
+		// repeated serially (same tables), a one-family serial walk that gave up (k_tokenize) is repeated with the
+		// part parsed again for both families.
+		auto gave_up = [&]() {
+			bool any = false;
+			for (int i = i0; i < i0 + cnt; ++i)
+				any = any || host_info[i].hops == WALK_GAVE_UP;
+			return any;
+		};
+		auto reset_part = [&]() -> int {
 			const long items = (long)cnt * FAM * LINK_SHARDS > (long)cnt * 48 * MAX_PLANES ? (long)cnt * FAM * LINK_SHARDS : (long)cnt * 48 * MAX_PLANES;
 			hipLaunchKernelGGL(k_part_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, h, cnt);
 			DWTX_HIP(hipMemsetAsync(h.symbits, 0, sizeof(unsigned) * (size_t)cnt * w.BW, st));
-			int rc2;
-			if ((rc2 = pre(st, i0, cnt, FAM)) || (rc2 = walk(st, i0, cnt, FAM)))
+			return DWTX_OK;
+		};
+		int rc2;
+		if (part_indexed[i0 ? 1 : 0] && gave_up()) {
+			if (getenv("DWTX_NO_INDEX_FALLBACK")) {   // test hook: shows that an index was turned down
+				dwtx_set_error("the sidecar index does not fit the stream (DWTX_NO_INDEX_FALLBACK forbids the serial walk)");
+				return DWTX_ERR_DEVICE;
+			}
+			if ((rc2 = reset_part()) || (rc2 = walk(st, i0, cnt, fam0, false)))
 				return rc2;
 			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
 			DWTX_HIP(hipStreamSynchronize(st));
 		}
+		if (gave_up()) {
+			if (getenv("DWTX_NO_SECOND_WALK")) {   // test hook: shows that a stream takes this path
+				dwtx_set_error("the one-family token walk gave up (DWTX_NO_SECOND_WALK forbids the second)");
+				return DWTX_ERR_DEVICE;
+			}
+			if ((rc2 = reset_part()) || (rc2 = pre(st, i0, cnt, FAM)) || (rc2 = walk(st, i0, cnt, FAM, false)))
+				return rc2;
+			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+			DWTX_HIP(hipStreamSynchronize(st));
+		}
+		if (ix_out)   // the index of every stream that was decoded to its end (the serial walk wrote it, the indexed one proved it)
+			for (int i = i0; i < i0 + cnt; ++i) {
+				dwtx_index &X = ix_out[i];
+				const DecInfo &D = reinterpret_cast<const DecInfo *>(host_info)[i];
+				X.magic = DWTX_INDEX_MAGIC;
+				X.W = W;
+				X.H = H;
+				X.C = C;
+				X.reserved = 0;
+				X.stream_bits = D.bits_used;
+				X.nsegs = !D.status && !D.truncated && g.levels_max >= g.levels && D.nsegs > 0 && D.nsegs <= MAX_SEGS ? D.nsegs : 0;
+				if (X.nsegs)
+					DWTX_HIP(hipMemcpy(X.seg, h.idx + (size_t)(i - i0) * MAX_SEGS, sizeof(SegIndex) * (size_t)X.nsegs, hipMemcpyDeviceToHost));
+			}
 		int pmax = 0;
 		for (int i = i0; i < i0 + cnt; ++i)
 			if (!host_info[i].status && host_info[i].pmax > pmax)
@@ -2013,12 +2326,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		return DWTX_OK;
 	};
 	int rc;
-	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
-	// (a test hook: it is the path a walk that gave up falls back to).
-	// One or two images leave most of the chip idle anyway: both families then, for the shorter walk.
-	const int fam0 = n <= 2 || getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
 	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
-		if ((rc = pre(s, 0, n, fam0)) || (rc = walk(s, 0, n, fam0)) || (rc = post(s, 0, n)))
+		if ((rc = pre(s, 0, n, fam0)) || (rc = walk(s, 0, n, fam0, indexed(0, n))) || (rc = post(s, 0, n)))
 			return rc;
 		return done ? done(user, 0, n, part_mask[0]) : DWTX_OK;
 	}
@@ -2030,7 +2339,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		return rc;
 	DWTX_HIP(hipEventRecord(ctx->ev[0], s));              // first half's tables done: its walk starts now
 	DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[0], 0));
-	if ((rc = walk(s, 0, na, fam0)) || (rc = pre(ctx->aux, na, n - na, fam0)) || (rc = walk(ctx->aux, na, n - na, fam0)))
+	if ((rc = walk(s, 0, na, fam0, indexed(0, na))) || (rc = pre(ctx->aux, na, n - na, fam0)) || (rc = walk(ctx->aux, na, n - na, fam0, indexed(na, n - na))))
 		return rc;
 	if ((rc = post(s, 0, na)) || (done && (rc = done(user, 0, na, part_mask[0]))))   // the first half's follow-up overlaps the second half's walk
 		return rc;

@@ -98,6 +98,33 @@ typedef struct dwtx_decode_info {
 	unsigned zeros_left;           /* run-length counter at the end; decode prints rle.h:45 "%d zeros not read." if > 1 */
 } dwtx_decode_info;
 
+/* ---- sidecar index ---------------------------------
+ * Not part of the reference and never inside a .dwt: an optional companion that records, for every
+ * (channel, level, plane) segment of decode.c:198-243's schedule, the decoder's state where the segment's first
+ * pass begins (decode.c:67-100: stream position, vli.h:24 order, rle.h:25 run counter, how many coefficients
+ * are still insignificant).  A decode that is given the index walks all segments at once instead of one after
+ * the other; it checks on the way that the segments fit together, so a wrong, stale or foreign index cannot
+ * change the result: the decoder then falls back to the plain walk.  A decode produces the index of every stream
+ * it decodes to its end. */
+#define DWTX_INDEX_MAGIC 0x49545744u   /* "DWTI" */
+#define DWTX_INDEX_MAX_SEGS 768         /* 3 channels x 16 levels x 16 planes */
+typedef struct dwtx_seg_index {
+	unsigned long long bit;            /* stream position of the segment's first pass */
+	unsigned long long sym_base;       /* decoder-internal: first symbol slot of the segment */
+	unsigned n1;                       /* symbols of the first pass */
+	unsigned cnt;                      /* rle.h:25 on entry */
+	unsigned desc;                     /* channel | level << 4 | (plane + 1) << 8 */
+	unsigned order;                    /* vli.h:24 on entry */
+} dwtx_seg_index;
+typedef struct dwtx_index {
+	unsigned magic;                    /* DWTX_INDEX_MAGIC */
+	int W, H, C;
+	int nsegs;                         /* 0: no index (stream unreadable, cut short, or decoded with a PIXELS cap) */
+	int reserved;
+	unsigned long long stream_bits;    /* bits of the stream the decoder used */
+	dwtx_seg_index seg[DWTX_INDEX_MAX_SEGS];
+} dwtx_index;
+
 /* ---- context / memory ---------------------------------------------------- */
 
 /* Create a context on HIP device `device` with a stream of its own. */
@@ -108,6 +135,11 @@ int dwtx_ctx_create_on_stream(int device, void *stream, dwtx_ctx **ctx);
 void dwtx_ctx_destroy(dwtx_ctx *ctx);
 const char *dwtx_last_error(void);
 int dwtx_sync(dwtx_ctx *ctx);
+/* Sidecar indices for the decode calls that follow on this context (dwtx_decode_planes / _device / _images):
+ * entry i of `in` (may be NULL) is offered for image i of a call, entry i of `out` (may be NULL) receives the
+ * index of image i (nsegs = 0 if it has none).  Both are host arrays that must stay valid until replaced;
+ * dwtx_ctx_set_index(ctx, NULL, NULL) ends it. */
+int dwtx_ctx_set_index(dwtx_ctx *ctx, const dwtx_index *in, dwtx_index *out);
 void *dwtx_stream(dwtx_ctx *ctx);
 
 void *dwtx_malloc(dwtx_ctx *ctx, size_t bytes);

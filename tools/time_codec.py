@@ -22,4 +22,15 @@ def timed(fn, reps=5):
 te = timed(lambda: ctx.encode_device(pix, out=streams, info=info))
 td = timed(lambda: ctx.decode_device(streams, lens, W, H, C, out=out))
 mp = n * W * H / 1e6
+if os.environ.get("TIME_INDEX"):   # the same decode with the sidecar index of a first decode (include/dwtx.h dwtx_index)
+    made = ctx.set_index(None, n)
+    ctx.decode_device(streams, lens, W, H, C, out=out)
+    torch.cuda.synchronize()
+    ctx.set_index(made, 0)
+    ctx.decode_device(streams, lens, W, H, C, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(n, H, W, C), pix)
+    ti = timed(lambda: ctx.decode_device(streams, lens, W, H, C, out=out))
+    ctx.set_index()
+    print(f"{W}x{H}x{C} x{n}: decode with index {ti:.2f} ms ({n * W * H / 1e6 / ti * 1e3:.0f} Mpx/s) against {td:.2f} ms without")
 print(f"{W}x{H}x{C} x{n}: encode {te:.2f} ms ({mp/te*1e3:.0f} Mpx/s)  decode {td:.2f} ms ({mp/td*1e3:.0f} Mpx/s)  round trip {mp/(te+td)*1e3:.0f} Mpx/s  bytes/frame {int(lens.sum())//n}")
