@@ -402,6 +402,22 @@ def main():
         if gathered is not None:
             result["gathered"] = gathered
 
+    def with_index(streams_dev, lens_dev, Wd, Hd, Cd, nd, out_dev, pix_dev):
+        """The same decode offered the sidecar index an earlier decode of these streams produced (include/dwtx.h
+        dwtx_index): ms per decode without / with it, and whether the pixels still come back."""
+        made = ctx.set_index(None, nd)
+        ctx.decode_device(streams_dev, lens_dev, Wd, Hd, Cd, out=out_dev)
+        torch.cuda.synchronize()
+        ctx.set_index()
+        plain = min(timed(lambda: ctx.decode_device(streams_dev, lens_dev, Wd, Hd, Cd, out=out_dev))[0] for _ in range(3))
+        ctx.set_index(made, 0)
+        ctx.decode_device(streams_dev, lens_dev, Wd, Hd, Cd, out=out_dev)
+        fast = min(timed(lambda: ctx.decode_device(streams_dev, lens_dev, Wd, Hd, Cd, out=out_dev))[0] for _ in range(3))
+        ctx.set_index()
+        same = bool(torch.equal(out_dev.view(nd, Hd, Wd, Cd), pix_dev))
+        return {"decode_ms": round(plain, 3), "decode_ms_with_sidecar_index": round(fast, 3), "segments_indexed": int(made[0].nsegs),
+                "lossless_with_index": same}
+
     if world == 1 and args.extras:
         # BASELINE.json configs[1] literally (one frame), configs[2] and configs[4] geometry (short runs)
         extras = {}
@@ -418,6 +434,7 @@ def main():
             "lossless": bool(torch.equal(d1.view(1, 4096, 4096, 1), one.pix)),
             "matches_reference_golden": golden_check("gray4096", s1[0, : int(l1[0])].cpu().numpy().tobytes()),
         }
+        result["single_frame"]["sidecar_index"] = with_index(one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, 1, one.dec, one.pix)
         del one, s1, d1
         for name in ("rgb1080p", "rgb4096"):
             if name == args.workload:
@@ -441,6 +458,7 @@ def main():
                 "coder_encode_frac_of_hbm_peak": cr["encode"]["frac_of_hbm_peak"],
                 "coder_decode_frac_of_hbm_peak": cr["decode"]["frac_of_hbm_peak"],
                 "coder_encode_ms": cr["encode"]["ms_per_step"], "coder_decode_ms": cr["decode"]["ms_per_step"],
+                "sidecar_index": with_index(r2.out[0], ctx.stream_lengths(r2.info[0]), r2.W, r2.H, r2.C, r2.B, r2.dec, r2.pix),
             }
             del r2, s2, d2
         result["workloads"] = extras

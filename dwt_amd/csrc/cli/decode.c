@@ -3,6 +3,11 @@
  *   decode input.dwt output.pnm [PIXELS]
  * Same argv, "-" for stdin/stdout, exit codes and output bytes, including
  * truncated streams (resolution drop, dequantisation bias) and the PIXELS cap.
+ *
+ * Beyond the reference (never needed, never changes the output): if a file "input.dwt.idx" lies beside the
+ * stream it is offered to the decoder as the stream's sidecar index (include/dwtx.h dwtx_index: all segments
+ * are then walked at once; an index that does not fit is noticed and ignored), and with DWTX_WRITE_INDEX set
+ * in the environment the decode leaves that file behind.
  */
 #include "../../../include/dwtx.h"
 #include "pnm_io.h"
@@ -53,6 +58,27 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%s\n", dwtx_last_error());
 		return 1;
 	}
+	/* the sidecar index: 32 header bytes + 32 per segment, as they lie in dwtx_index */
+	dwtx_index *ix_in = NULL, *ix_out = NULL;
+	char *iname = NULL;
+	if (strcmp(argv[1], "-")) {
+		iname = (char *)malloc(strlen(argv[1]) + 5);
+		sprintf(iname, "%s.idx", argv[1]);
+		FILE *fi = fopen(iname, "rb");
+		if (fi) {
+			ix_in = (dwtx_index *)calloc(1, sizeof(dwtx_index));
+			const size_t head = sizeof(dwtx_index) - sizeof(ix_in->seg);
+			if (fread(ix_in, 1, head, fi) != head || ix_in->magic != DWTX_INDEX_MAGIC || ix_in->nsegs <= 0 ||
+				ix_in->nsegs > DWTX_INDEX_MAX_SEGS || fread(ix_in->seg, sizeof(dwtx_seg_index), (size_t)ix_in->nsegs, fi) != (size_t)ix_in->nsegs) {
+				free(ix_in);
+				ix_in = NULL;
+			}
+			fclose(fi);
+		}
+		if (getenv("DWTX_WRITE_INDEX"))
+			ix_out = (dwtx_index *)calloc(1, sizeof(dwtx_index));
+	}
+	dwtx_ctx_set_index(ctx, ix_in, ix_out);
 	int ow, oh, oc;
 	dwtx_decode_info info;
 	int rc = dwtx_decode_images_info(ctx, padded, stride, &len, 1, pixels_max, pix, (size_t)W * H * C, &ow, &oh, &oc, &info);
@@ -70,6 +96,17 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%u zeros not read.\n", info.zeros_left);
 	if (!pnm_write(argv[2], pix, ow, oh, oc))
 		return 1;
+	if (ix_out && ix_out->nsegs > 0) {
+		FILE *fo = fopen(iname, "wb");
+		if (fo) {
+			fwrite(ix_out, 1, sizeof(dwtx_index) - sizeof(ix_out->seg), fo);
+			fwrite(ix_out->seg, sizeof(dwtx_seg_index), (size_t)ix_out->nsegs, fo);
+			fclose(fo);
+		}
+	}
+	free(ix_in);
+	free(ix_out);
+	free(iname);
 	dwtx_ctx_destroy(ctx);
 	free(padded);
 	free(pix);

@@ -262,3 +262,35 @@ def test_argument_errors_match_the_reference_binaries(tmp_path, args):
         r = subprocess.run([ref] + a, cwd=tmp_path, capture_output=True, timeout=300)
         assert m.returncode == (1 if r.returncode < 0 else r.returncode), (m.stderr, r.stderr)
         assert m.stderr.replace(mine.encode(), b"PROG") == r.stderr.replace(ref.encode(), b"PROG")
+
+
+def test_decode_leaves_and_takes_a_sidecar_index(tmp_path):
+    """Beyond the reference: `decode` with DWTX_WRITE_INDEX leaves input.dwt.idx behind; a later decode finds it
+    and walks the segments at once.  The output never depends on it (a damaged or foreign index is ignored)."""
+    import shutil
+
+    dwt, pnm = str(tmp_path / "a.dwt"), str(tmp_path / "a.pnm")
+    shutil.copy(os.path.join(orc.GOLDEN, "smpte.dwt"), dwt)
+    want = orc.read_pnm(SMPTE)
+
+    def decode(**env):
+        r = subprocess.run([DEC, dwt, pnm], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-300:]
+        assert r.stderr == b""
+        assert (orc.read_pnm(pnm) == want).all()
+
+    decode()
+    assert not os.path.exists(dwt + ".idx")
+    decode(DWTX_WRITE_INDEX="1")
+    idx = open(dwt + ".idx", "rb").read()
+    assert idx[:4] == b"DWTI" and len(idx) == 32 + 32 * int.from_bytes(idx[16:20], "little")
+    decode(DWTX_NO_INDEX_FALLBACK="1")            # the index is accepted (a rejected one would be an error here)
+    open(dwt + ".idx", "wb").write(idx[:200] + bytes(len(idx) - 200))
+    decode()                                      # damaged: ignored
+    r = subprocess.run([DEC, dwt, pnm], capture_output=True, timeout=300, env=dict(os.environ, DWTX_NO_INDEX_FALLBACK="1"))
+    assert r.returncode == 1                      # ... and that it was the fallback shows here
+    open(dwt + ".idx", "wb").write(idx[:20])
+    decode()                                      # cut short: not even read
+    open(dwt + ".idx", "wb").write(idx)
+    r = run(DEC, dwt, pnm, "300")                 # a PIXELS cap: the plain walk, same picture as ever
+    assert r.returncode == 0 and (orc.read_pnm(pnm) == orc.decode(open(dwt, "rb").read(), 300)).all()
