@@ -291,6 +291,9 @@ def main():
                          **{f"rank{r}": bufs[r].cpu().numpy() for r in range(world)})
 
     # ---- roofline of the lifting kernels, HIP events on the kernels' stream --------
+    # (fresh allocations: three planes-sized tensors carved out of one cached multi-gigabyte block make the forward
+    # kernel 12 % slower than separately allocated ones — tools/lift_offsets.py vs tools/time_lift.py)
+    torch.cuda.empty_cache()
     planes = ctx.planes_from_pixels(pix)
     pyr = torch.empty_like(planes)
     back = torch.empty_like(planes)
