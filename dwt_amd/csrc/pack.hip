@@ -602,7 +602,8 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *wsum, 
 		wsum[wv] = inc;
 	__syncthreads();
 	unsigned woff = 0, all = 0;
-	for (int k = 0; k < 16; ++k) {
+	const int waves = (int)blockDim.x >> 6;
+	for (int k = 0; k < waves; ++k) {
 		const unsigned s = wsum[k];
 		woff += k < wv ? s : 0u;
 		all += s;
@@ -1104,7 +1105,8 @@ __device__ __forceinline__ RunMap block_scan_maps(RunMap m, RunMap *wagg, RunMap
 		wagg[wv] = m;
 	__syncthreads();
 	RunMap pre = { 1u, 0u }, all = { 1u, 0u };
-	for (int k = 0; k < 16; ++k) {
+	const int waves = (int)blockDim.x >> 6;
+	for (int k = 0; k < waves; ++k) {
 		const RunMap a = wagg[k];
 		if (k < wv)
 			pre = compose(pre, a);
@@ -1115,18 +1117,25 @@ __device__ __forceinline__ RunMap block_scan_maps(RunMap m, RunMap *wagg, RunMap
 	return compose(pre, m);
 }
 
-__global__ __launch_bounds__(CARRY_BLOCK) void k_carry_local(Work w)
+// The blocks of 1024 entries are scanned by 256 threads with four consecutive entries each: a quarter of the waves
+// and of the barriers for the same entries (the kernels wait on both, not on memory).
+constexpr int CARRY_PER = 4, CARRY_THREADS = CARRY_BLOCK / CARRY_PER;
+
+__global__ __launch_bounds__(CARRY_THREADS) void k_carry_local(Work w)
 {
 	__shared__ RunMap wagg[16];
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
 	if ((int)blockIdx.x * CARRY_BLOCK >= I.E)
 		return;
-	const int e = blockIdx.x * CARRY_BLOCK + threadIdx.x;
-	bool has_one, seg_end, refs;
-	RunMap t = carry_map_of(w, I, img, e, has_one, seg_end, refs);
-	if (refs)
-		t = RunMap{ 0u, 0u };   // the break slot takes the pending run, the next segment starts from 0
+	const int e0 = blockIdx.x * CARRY_BLOCK + threadIdx.x * CARRY_PER;
+	RunMap t = { 1u, 0u };
+#pragma unroll
+	for (int j = 0; j < CARRY_PER; ++j) {
+		bool has_one, seg_end, refs;
+		const RunMap m = carry_map_of(w, I, img, e0 + j, has_one, seg_end, refs);
+		t = compose(t, refs ? RunMap{ 0u, 0u } : m);   // the break slot takes the pending run, the next segment starts from 0
+	}
 	RunMap total;
 	block_scan_maps(t, wagg, total);
 	if (threadIdx.x == 0)
@@ -1164,17 +1173,22 @@ __global__ __launch_bounds__(CARRY_BLOCK) void k_carry_blocks(Work w)
 		token_store(w, img, I.T - 1, s, T_NOSIGN);   // encode.c:221 rle_flush: always emitted
 }
 
-__global__ __launch_bounds__(CARRY_BLOCK) void k_carry_apply(Work w)
+__global__ __launch_bounds__(CARRY_THREADS) void k_carry_apply(Work w)
 {
 	__shared__ RunMap wagg[16];
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
 	if ((int)blockIdx.x * CARRY_BLOCK >= I.E)
 		return;
-	const int e = blockIdx.x * CARRY_BLOCK + threadIdx.x;
-	bool has_one, seg_end, refs;
-	const RunMap own = carry_map_of(w, I, img, e, has_one, seg_end, refs);
-	const RunMap t = refs ? RunMap{ 0u, 0u } : own;
+	const int e0 = blockIdx.x * CARRY_BLOCK + threadIdx.x * CARRY_PER;
+	RunMap own[CARRY_PER];
+	bool has_one[CARRY_PER], seg_end[CARRY_PER], refs[CARRY_PER];
+	RunMap t = { 1u, 0u };
+#pragma unroll
+	for (int j = 0; j < CARRY_PER; ++j) {
+		own[j] = carry_map_of(w, I, img, e0 + j, has_one[j], seg_end[j], refs[j]);
+		t = compose(t, refs[j] ? RunMap{ 0u, 0u } : own[j]);
+	}
 	RunMap total;
 	const RunMap inc = block_scan_maps(t, wagg, total);
 	RunMap ex;
@@ -1186,18 +1200,22 @@ __global__ __launch_bounds__(CARRY_BLOCK) void k_carry_apply(Work w)
 	__syncthreads();
 	if ((threadIdx.x & 63) == 0)
 		ex = threadIdx.x ? edge[(threadIdx.x >> 6) - 1] : RunMap{ 1u, 0u };
-	if (e >= I.E)
-		return;
 	const unsigned s_blk = w.carry_in[img * w.NCB + blockIdx.x];
-	const unsigned s_in = ex.add + (ex.keep ? s_blk : 0u);
-	const unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
-	if (has_one && s_in) {   // the entry's first token: its run began before this tile
-		const unsigned tk = w.tok16[img * w.TS + tb];
-		token_store(w, img, tb, (tk & T_RUN) + s_in, tk & ~T_RUN);
-	}
-	if (seg_end) {   // the break slot
-		const unsigned s = own.add + (own.keep ? s_in : 0u);
-		token_store(w, img, tb + w.ent_ones[img * w.ES + e], s, T_BREAK | T_NOSIGN | ((refs && s) ? 0u : T_VOID));
+	unsigned s_in = ex.add + (ex.keep ? s_blk : 0u);   // the pending run entering this thread's first entry
+#pragma unroll
+	for (int j = 0; j < CARRY_PER; ++j) {
+		const int e = e0 + j;
+		if (e >= I.E)
+			break;
+		const unsigned tb = w.ent_tokbase[img * (w.ES + 1) + e];
+		if (has_one[j] && s_in) {   // the entry's first token: its run began before this tile
+			const unsigned tk = w.tok16[img * w.TS + tb];
+			token_store(w, img, tb, (tk & T_RUN) + s_in, tk & ~T_RUN);
+		}
+		const unsigned s_out = own[j].add + (own[j].keep ? s_in : 0u);
+		if (seg_end[j])   // the break slot
+			token_store(w, img, tb + w.ent_ones[img * w.ES + e], s_out, T_BREAK | T_NOSIGN | ((refs[j] && s_out) ? 0u : T_VOID));
+		s_in = refs[j] ? 0u : s_out;
 	}
 }
 
@@ -2090,9 +2108,9 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_stage_zero, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_code, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
-	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
 	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
-	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
 	hipLaunchKernelGGL(k_gorder, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
 	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
 	hipLaunchKernelGGL(k_lut, dim3(512, n), dim3(256), 0, s, w);

@@ -9,13 +9,13 @@ W = H = 4096
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ctx = dwt_amd.Context(0)
 n = P * H * W
-big = torch.empty(3 * n + (64 << 20), dtype=torch.int32, device="cuda")
+big = torch.empty(5 * n + (64 << 20), dtype=torch.int32, device="cuda")
 src = big[:n].view(P, H, W)
 src.copy_(torch.randint(0, 256, (P, H, W), dtype=torch.int32, device="cuda"))
-for gap in (0, 256, 4096, 65536, 1 << 20, (1 << 20) + 4096, 3 << 20, 16 << 20, (16 << 20) + 8192):
+for gap in (0, 4096, 1 << 20, 16 << 20, 128 << 20, 512 << 20, (512 << 20) + (3 << 20), 1 << 30, (1 << 30) + (640 << 20), 2 << 30, (3 << 30) + (5 << 20)):
     g = gap // 4
     pyr = big[n + g:2 * n + g].view(P, H, W)
-    back = big[2 * n + 2 * g:3 * n + 2 * g].view(P, H, W)
+    back = big[4 * n:5 * n].view(P, H, W)
     res = []
     for name, fn in (("fwd", lambda: ctx.transformation_fwd(src, pyr)), ("inv", lambda: ctx.transformation_inv(pyr, back))):
         fn(); torch.cuda.synchronize()
