@@ -227,6 +227,60 @@ struct BitReader {
 		b += need;
 		return true;
 	}
+	// bits.h:94-106 for any n, as the reference's binary does it: bit i lands at position i modulo 32
+	__device__ bool read_any(unsigned n, unsigned &v)
+	{
+		if (n <= 32u)
+			return read((int)n, v);
+		unsigned a = 0;
+		for (unsigned i = 0; i < n; ++i) {
+			unsigned bit;
+			if (!read(1, bit))
+				return false;
+			a |= bit << (i & 31u);
+		}
+		v = a;
+		return true;
+	}
+	// The same for any bits at all, as the reference's binary reads them (only damaged streams get here: the
+	// order passes 31).  vli.h:90-91 adds 1 << order per zero and bits.h:100 ORs bit << i: x86 takes both shift
+	// counts modulo 32 and the sums wrap, and a negative result is an error to every caller (rle.h:72,
+	// decode.c:122) — the decode stops there, quietly, while running out of data prints bytes.h:101.
+	// 0: value read, 1: end of data, 2: the reference's reader returns a negative number.
+	__device__ int vli_any(int &order, unsigned &val)
+	{
+		if (vli(order, val))
+			return 0;
+		unsigned ord = (unsigned)order, sum = 0;
+		for (;;) {
+			if (avail() >= 64 && !peek()) {   // 64 zeros: every shift count modulo 32 occurs twice
+				sum += 2u * 0xffffffffu;
+				ord += 64;
+				b += 64;
+				continue;
+			}
+			unsigned bit;
+			if (!read(1, bit))
+				return 1;
+			if (bit)
+				break;
+			sum += 1u << (ord & 31u);
+			++ord;
+		}
+		unsigned a = 0;
+		for (unsigned i = 0; i < ord; ++i) {
+			unsigned bit;
+			if (!read(1, bit))
+				return 1;
+			a |= bit << (i & 31u);
+		}
+		order = ord >= 2u ? (int)(ord - 2u) : 0;
+		const int v = (int)(a + sum);
+		if (v < 0)
+			return 2;
+		val = (unsigned)v;
+		return 0;
+	}
 };
 
 // Pass-1 symbols that are ones, two bits per symbol in one array: bit 2P = "symbol P is a one",
@@ -982,12 +1036,12 @@ __device__ bool read_preamble(BitReader &br, const UnpackGeom &g, const unsigned
 	order = 0;
 	for (int c = 0; c < g.C; ++c) {
 		unsigned cnt;
-		if (!br.vli(order, cnt))
+		if (br.vli_any(order, cnt))
 			return false;
 		if (cnt)
 			for (int i = 0; i < g.pixels[0]; ++i) {
 				unsigned v, neg = 0;
-				if (cnt > 32 || !br.read((int)cnt, v))
+				if (!br.read_any(cnt, v))
 					return false;
 				if (v && !br.read(1, neg))
 					return false;
@@ -997,7 +1051,7 @@ __device__ bool read_preamble(BitReader &br, const UnpackGeom &g, const unsigned
 	}
 	for (int c = 0; c < g.C; ++c) {
 		unsigned p;
-		if (!br.vli(order, p) || p > MAX_PLANES)
+		if (br.vli_any(order, p) || p > MAX_PLANES)
 			return false;
 		planes[c] = (int)p;
 	}
@@ -1340,9 +1394,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					br_synced = true;
 				}
 				unsigned v;
-				if (!br.vli(order, v)) {
+				const int bad = br.vli_any(order, v);
+				if (bad) {
 					ok = false;
-					eof = true;
+					eof = bad == 1;
 					break;
 				}
 				++walked;

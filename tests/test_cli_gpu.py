@@ -294,3 +294,14 @@ def test_decode_leaves_and_takes_a_sidecar_index(tmp_path):
     open(dwt + ".idx", "wb").write(idx)
     r = run(DEC, dwt, pnm, "300")                 # a PIXELS cap: the plain walk, same picture as ever
     assert r.returncode == 0 and (orc.read_pnm(pnm) == orc.decode(open(dwt, "rb").read(), 300)).all()
+
+
+@pytest.mark.parametrize("name,said", [("damaged_order_beyond_31_47x650x1.dwt", b""), ("damaged_wide_root_213x18x3.dwt", b"509 zeros not read.\n")])
+def test_damaged_streams_decode_like_the_reference_binary(tmp_path, name, said):
+    """tests/test_oracle.py::test_damaged_streams_that_leave_the_range_of_the_shifts, through the CLI: same exit
+    code, same (empty) stderr, same picture as the oracle's."""
+    src = os.path.join(orc.GOLDEN, name)
+    pnm = str(tmp_path / "a.pnm")
+    r = run(DEC, src, pnm)
+    assert r.returncode == 0 and r.stderr == said   # what oracle/_ref/decode says (tests/test_oracle.py pins it)
+    assert (orc.read_pnm(pnm) == orc.decode(open(src, "rb").read())).all()

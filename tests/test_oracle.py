@@ -185,6 +185,27 @@ def test_corrupted_streams_against_reference_binary(tmp_path):
             assert back is not None and ref.shape == back.shape and (ref == back).all()
 
 
+DAMAGED = [("damaged_order_beyond_31_47x650x1.dwt", 47, 650, 1, b""), ("damaged_wide_root_213x18x3.dwt", 213, 18, 3, b"509 zeros not read.\n")]
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("case", DAMAGED)
+def test_damaged_streams_that_leave_the_range_of_the_shifts(tmp_path, case):
+    """Two damaged streams a seeded sweep found (tools/fuzz_decode.py): in one the VLI order passes 31 (vli.h:90-91
+    shifts by it), in the other the root image claims more than 32 bits per coefficient (bits.h:100 shifts by the
+    bit index).  Both are undefined in C; what the reference's binary does (x86: shift counts modulo 32) is what
+    the restatement and the GPU decoder (tests/test_unpack_gpu.py) have to do."""
+    name, W, H, Cn, said = case
+    blob = open(os.path.join(orc.GOLDEN, name), "rb").read()
+    dwt, dec = str(tmp_path / "d.dwt"), str(tmp_path / "d.pnm")
+    open(dwt, "wb").write(blob)
+    r = subprocess.run([os.path.join(orc.REF_DIR, "decode"), dwt, dec], capture_output=True, timeout=120)
+    assert r.returncode == 0 and r.stderr == said   # the reference decodes them to the end of its schedule, no "end of file"
+    back = orc.decode(blob)
+    ref = orc.read_pnm(dec)
+    assert back is not None and ref.shape == back.shape and (ref == back).all()
+
+
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
 def test_statistics_lines_under_tiny_capacities_against_reference_binary(tmp_path):
     """With CAPACITY below header + root image the reference's three stderr numbers are its bit writer's

@@ -96,3 +96,17 @@ def test_both_path_families_from_the_start(ctx, shape, monkeypatch):
         if ref is None or max(ref[3]) <= 16:
             blobs.append(blob)
     check(ctx, blobs, W, H, Cn)
+
+
+@pytest.mark.parametrize("case", [("damaged_order_beyond_31_47x650x1.dwt", 47, 650, 1), ("damaged_wide_root_213x18x3.dwt", 213, 18, 3)])
+def test_damaged_streams_that_leave_the_range_of_the_shifts(ctx, case):
+    """See tests/test_oracle.py (same name): the VLI order passes 31 / the root image claims more than 32 bits per
+    coefficient.  The decoder reads such tokens bit by bit the way the reference's binary does; alone, in a batch,
+    with both path families."""
+    import os
+
+    name, W, H, Cn = case
+    blob = open(os.path.join(orc.GOLDEN, name), "rb").read()
+    good, _ = orc.encode(orc.synth(W, H, Cn, 3, 0))
+    check(ctx, [blob], W, H, Cn)
+    check(ctx, [good, blob, blob[:len(blob) * 2 // 3], blob, good], W, H, Cn)
