@@ -245,8 +245,8 @@ class Context:
         ow, oh, oc = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
         rc = self.lib.dwtx_decode_images(self.h, host.ctypes.data, stride, C.cast(lens, C.c_void_p), n, pixels_max,
                                          pix.ctypes.data, pstride, ow, oh, oc)
-        if rc == -1 and single:
-            return None
+        if rc == -1 and n == 1:   # one unreadable stream is an error code (decode.c exits 1), in a batch it is a missing picture
+            return None if single else [None]
         _check(rc, "dwtx_decode_images")
         outs = [pix[i, : ow[i] * oh[i] * oc[i]].reshape(oh[i], ow[i], oc[i]).copy() if ow[i] else None for i in range(n)]
         return outs[0] if single else outs

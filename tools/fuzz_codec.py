@@ -1,0 +1,48 @@
+"""Longer seeded sweep of the whole codec against the oracle (development aid, GPU box; not part of the test suite):
+random geometries (incl. power-of-two squares and widths that take the fused 8-bit paths), batches, capacities,
+PIXELS caps — stream bytes, statistics and decoded pictures.   tools/fuzz_codec.py [seed] [cases]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import orc
+import dwt_amd
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rng = np.random.default_rng(seed)
+ctx = dwt_amd.Context(0)
+t0 = time.time()
+frames = 0
+for case in range(cases):
+    W, H = int(rng.integers(8, 700)), int(rng.integers(8, 700))
+    kind = case % 5
+    if kind == 0:
+        W = H = int(2 ** rng.integers(3, 11))
+    elif kind == 1:
+        W = (W + 3) // 4 * 4
+    Cn = 1 if rng.integers(0, 2) else 3
+    n = int(rng.integers(1, 7))
+    pix = np.stack([orc.synth(W, H, Cn, int(rng.integers(0, 1 << 30)), int(rng.integers(0, 2))) for _ in range(n)])
+    want = [orc.encode(p) for p in pix]
+    streams, stats = ctx.encode(pix)
+    for i in range(n):
+        assert streams[i] == want[i][0], ("bytes", case, i, W, H, Cn)
+        assert (stats[i].meta_bits, stats[i].root_bits, stats[i].total_bits) == (want[i][1].meta_bits, want[i][1].root_bits, want[i][1].total_bits), ("stats", case, i)
+    outs = ctx.decode(streams)
+    assert all((o == p).all() for o, p in zip(outs, pix)), ("roundtrip", case, W, H, Cn)
+    cap = int(rng.integers(7, max(8, len(streams[0]))))
+    cut, cstats = ctx.encode(pix, cap)
+    for i in range(n):
+        w2, s2 = orc.encode(pix[i], cap)
+        assert cut[i] == w2, ("capacity bytes", case, i, W, H, Cn, cap)
+        assert (cstats[i].meta_bits, cstats[i].root_bits, cstats[i].total_bits) == (s2.meta_bits, s2.root_bits, s2.total_bits), ("capacity stats", case, i, cap)
+    px = int(rng.integers(0, 3 * W * H))
+    for blobs, cap_px in ((cut, -1), (streams, px), ([s[: max(1, len(s) // 3)] for s in streams], -1)):
+        got = ctx.decode(list(blobs), cap_px)
+        for i, b in enumerate(blobs):
+            ref = orc.decode(b, cap_px)
+            assert (ref is None and got[i] is None) or (got[i] is not None and got[i].shape == ref.shape and (got[i] == ref).all()), ("decode", case, i, W, H, Cn, cap, cap_px)
+    frames += n
+print(f"seed {seed}: {cases} cases, {frames} frames: bytes, statistics and pictures equal the oracle, {time.time() - t0:.0f} s")
