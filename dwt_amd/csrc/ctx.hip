@@ -82,6 +82,12 @@ extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 	for (int i = 0; i < DWTX_SCRATCH_SLOTS; ++i)
 		if (c->scratch[i])
 			(void)hipFree(c->scratch[i]);
+	if (c->have_more) {
+		for (int i = 0; i < 2; ++i)
+			(void)hipStreamDestroy(c->more[i]);
+		for (int i = 0; i < 8; ++i)
+			(void)hipEventDestroy(c->pev[i]);
+	}
 	if (c->have_aux) {
 		(void)hipStreamDestroy(c->aux);
 		for (int i = 0; i < 4; ++i)

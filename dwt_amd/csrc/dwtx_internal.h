@@ -20,6 +20,9 @@ struct dwtx_ctx {
 	hipStream_t aux;       // second stream: half of a decode batch runs here so that one half's serial
 	hipEvent_t ev[4];      // token walk overlaps the other half's parallel kernels (unpack.hip); [2],[3]: bitmap clear
 	bool have_aux;
+	hipStream_t more[2];   // decode batches of small pictures run as four parts, one stream each (unpack.hip)
+	hipEvent_t pev[8];     // [k] part k's chunk tables done, [4+k] part k's scatter done
+	bool have_more;
 	hipStream_t copy;      // host-buffer wrappers: transfers of one part of a batch overlap the kernels of another (codec.hip)
 	hipEvent_t cev[6];
 	bool have_copy;
