@@ -1841,7 +1841,12 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	// wave fetches the slices of up to AP_BATCH planes as coalesced rows and keeps them in LDS: all those round
 	// trips overlap instead of two dependent ones per plane.
 	constexpr int AP_BATCH = 8, SYMW = 66, REFW = 34;
-	__shared__ unsigned ap_sym[4][AP_BATCH][SYMW], ap_ref[4][AP_BATCH][REFW];
+	// (one 4 KB stretch of LDS per wave holds these slices and, once all planes are in, the square that is staged for
+	// the store: 20 KB per workgroup instead of 34, six waves per SIMD instead of four)
+	static_assert(AP_BATCH * (SYMW + REFW) <= SQ_WORDS, "the plane slices share the wave's square staging area");
+	__shared__ __attribute__((aligned(16))) unsigned ap_mem[4][SQ_WORDS];
+	unsigned (*ap_sym)[SYMW] = reinterpret_cast<unsigned (*)[SYMW]>(ap_mem[threadIdx.x >> 6]);
+	unsigned (*ap_ref)[REFW] = reinterpret_cast<unsigned (*)[REFW]>(ap_mem[threadIdx.x >> 6] + AP_BATCH * SYMW);
 	__shared__ unsigned ap_rank[4][MAX_PLANES], ap_n2[4][MAX_PLANES], ap_refbit[4][MAX_PLANES];
 	const int wv = threadIdx.x >> 6;
 	unsigned my_tr = 0, my_n2 = 0;
@@ -1901,11 +1906,11 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 		for (int q = 0; q < AP_BATCH; ++q) {
 			if (pl[q] < 0)
 				continue;
-			ap_sym[wv][q][lane] = sv0[q];
+			ap_sym[q][lane] = sv0[q];
 			if (lane < SYMW - 64)
-				ap_sym[wv][q][64 + lane] = sv1[q];
+				ap_sym[q][64 + lane] = sv1[q];
 			if (lane < REFW)
-				ap_ref[wv][q][lane] = rv[q];
+				ap_ref[q][lane] = rv[q];
 		}
 		sq_wave_sync();
 		// ---- the planes of the batch, in order ----
@@ -1919,7 +1924,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			const unsigned nb = wave_incl_add_u(ci) - ci;                 // insignificant coefficients in the lanes before
 			// symbols: two bits each (one flag, sign), this lane's start `nb` symbols after the tile's
 			const unsigned srel = (rank & 15u) + nb;
-			const unsigned *sw = ap_sym[wv][q] + (srel >> 4);
+			const unsigned *sw = ap_sym[q] + (srel >> 4);
 			unsigned s32 = __builtin_amdgcn_alignbit(sw[1], sw[0], (srel & 15u) * 2u);
 			// refinement bits that the stream still holds for this lane (a truncated stream ends inside some block)
 			const unsigned sb4 = (unsigned)vb - nb;                          // significant coefficients in the lanes before
@@ -1927,7 +1932,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			const unsigned cs = (unsigned)nv - ci;
 			const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
 			const unsigned rrel = ap_refbit[wv][p] + sb4;
-			const unsigned *rwp = ap_ref[wv][q] + (rrel >> 5);
+			const unsigned *rwp = ap_ref[q] + (rrel >> 5);
 			unsigned r16 = __builtin_amdgcn_alignbit(rwp[1], rwp[0], rrel & 31u) & ((1u << avail) - 1u);   // avail <= 16
 			// four coefficients per look-up: symbols to the insignificant ones, refinement bits to the others, in order
 			const unsigned sig = valid16 & ~ins;
@@ -1954,7 +1959,6 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	if ((g.sq_levels >> l) & 1u) {
 		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
 		// with the dead-zone bias of planes that were never decoded (decode.c:51-58)
-		__shared__ __attribute__((aligned(16))) unsigned sq_lds[4][SQ_WORDS];
 		const int m = I.missing[c * 16 + l] - 2;
 		const int bias = m >= 0 ? 1 << m : 0;
 		int val[16];
@@ -1965,7 +1969,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 				v += v < 0 ? -bias : bias;
 			val[i] = v;
 		}
-		store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], j, lane, sq_lds[threadIdx.x >> 6], val);
+		store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], j, lane, ap_mem[threadIdx.x >> 6], val);
 		return;
 	}
 	int *dst = lin + (long)plane * g.lin_stride + base + first;
