@@ -1250,6 +1250,33 @@ __device__ __forceinline__ void stage_tokens(unsigned *rows, const unsigned shor
 	}
 }
 
+// The same for one half of every group: tokens [32 * half, 32 * half + 32) of the 64 groups of the wave's stretch, one
+// row of 16 dwords per group (pitch 18: lane j's ds_read_b64 of its q-th quad hits bank pair 18j + 2q, all different
+// over 32 lanes).  k_emit walks its tokens once, front to back: staging them half by half halves its LDS.
+constexpr int HROW = 18;
+
+__device__ __forceinline__ void stage_tokens_half(unsigned *rows, const unsigned short *tok16, long t0, long T, int lane, int half)
+{
+#pragma unroll
+	for (int it = 0; it < 4; ++it) {
+		const int grp = it * 16 + (lane >> 2), piece = lane & 3;   // 16 bytes = 8 tokens per lane
+		const long t = t0 + grp * 64 + half * 32 + piece * 8;
+		uint4 v = make_uint4(VOID2, VOID2, VOID2, VOID2);
+		if (t >= 0 && t + 8 <= T) {
+			v = *reinterpret_cast<const uint4 *>(tok16 + t);
+		} else if (t + 8 > 0 && t < T) {
+			unsigned h[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e)
+				h[e] = t + e >= 0 && t + e < T ? (unsigned)tok16[t + e] : (T_VOID | T_NOSIGN);
+			v = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+		}
+		unsigned *dst = rows + grp * HROW + piece * 4;
+		*reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+		*reinterpret_cast<uint2 *>(dst + 2) = make_uint2(v.z, v.w);
+	}
+}
+
 // a token pair holds an escape (run field 0xfff) / a break slot
 __device__ __forceinline__ bool pair_has_esc(unsigned x) { return (((x & 0x0fff0fffu) + 0x00010001u) & 0x10001000u) != 0u; }
 __device__ __forceinline__ bool pair_has_break(unsigned x) { return (x & (T_BREAK * 0x00010001u)) != 0u; }
@@ -1651,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_gorder_exact(Work w)
 constexpr int EWIN = 768;
 
 struct EmitLds {
-	unsigned tok[64 * WROW];
+	unsigned tok[64 * HROW];   // half of every group's tokens at a time (stage_tokens_half)
 	unsigned win[EWIN];
 };
 
@@ -1671,7 +1698,6 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 	const unsigned *srefs = w.seg_refs + (long)img * MAX_SEGS;
 	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS;
 	unsigned *rows = lds[wv].tok, *win = lds[wv].win;
-	stage_tokens(rows, tok16, wave * CHUNK, T, lane);
 	for (int i = lane; i < EWIN; i += 64)
 		win[i] = 0u;
 	const long S = wave * 64 + lane;
@@ -1708,7 +1734,7 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 			fill -= 32;
 		}
 	};
-	const unsigned *my = rows + lane * WROW;
+	const unsigned *my = rows + lane * HROW;
 	const long tb = S * SUB;
 	// one token, the general way: up to 64 code bits, break slots, escapes
 	auto slow_token = [&](unsigned tk, long t) {
@@ -1755,10 +1781,17 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 		len = vd ? 0 : l;
 		o = vd ? o : (top >= 2 ? top - 2 : 0);
 	};
-	if (live) {
+	for (int half = 0; half < 2; ++half) {   // (uniform: every lane of the wave takes part in the staging)
+		if (half)
+			wave_sync();   // the first half's rows have been read
+		stage_tokens_half(rows, tok16, wave * CHUNK, T, lane, half);
+		wave_sync();
+		if (!live)
+			continue;
 #pragma unroll 2
-		for (int q = 0; q < 16; ++q) {
-			const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+		for (int q8 = 0; q8 < 8; ++q8) {
+			const int q = half * 8 + q8;
+			const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q8);
 			const unsigned xs[2] = { x2.x, x2.y };
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
@@ -1783,8 +1816,9 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 				}
 			}
 		}
-		put_word(widx, (unsigned)acc);
 	}
+	if (live)
+		put_word(widx, (unsigned)acc);
 	// the window to memory: the words strictly inside the wave's stretch are its own
 	const long nlive = ngroups - wave * 64 < 64 ? ngroups - wave * 64 : 64;
 	const long endw = __shfl(widx, (int)nlive - 1);   // word of the last bit position (shared with whatever follows)
