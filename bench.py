@@ -405,7 +405,7 @@ def main():
         if gathered is not None:
             result["gathered"] = gathered
 
-    def with_index(streams_dev, lens_dev, Wd, Hd, Cd, nd, out_dev, pix_dev):
+    def with_index(ctx, streams_dev, lens_dev, Wd, Hd, Cd, nd, out_dev, pix_dev):
         """The same decode offered the sidecar index an earlier decode of these streams produced (include/dwtx.h
         dwtx_index): ms per decode without / with it, and whether the pixels still come back."""
         made = ctx.set_index(None, nd)
@@ -437,33 +437,39 @@ def main():
             "lossless": bool(torch.equal(d1.view(1, 4096, 4096, 1), one.pix)),
             "matches_reference_golden": golden_check("gray4096", s1[0, : int(l1[0])].cpu().numpy().tobytes()),
         }
-        result["single_frame"]["sidecar_index"] = with_index(one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, 1, one.dec, one.pix)
+        result["single_frame"]["sidecar_index"] = with_index(ctx, one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, 1, one.dec, one.pix)
         del one, s1, d1
         for name in ("rgb1080p", "rgb4096"):
             if name == args.workload:
                 continue
             torch.cuda.empty_cache()
-            r2 = Runner(ctx, torch, dwt_amd, name, 0, 0, 1, dev)
-            t2, (s2, l2, d2, i2), _ = r2.timed(3, 1, fence)
+            # a context of its own: scratch sized and placed for this workload, as when it is the main one (inside the
+            # scratch the gray batch left behind, 16 frames of 4096x4096 RGB ran anywhere between 18.5 and 27 ms per step)
+            cx = dwt_amd.Context(local)
+            r2 = Runner(cx, torch, dwt_amd, name, 0, 0, 1, dev)
+            XS = 6   # steps of a side workload (2 warm-up steps: a 3-step run once caught a cold start and read 30 % low)
+            t2, (s2, l2, d2, i2), _ = r2.timed(XS, 2, fence)
             ok2 = bool(torch.equal(d2.view(r2.B, r2.H, r2.W, r2.C), r2.pix)) and all(i.status == 0 and not i.truncated for i in i2)
             g2 = golden_check(name, s2[0, : int(l2[0])].cpu().numpy().tobytes())
-            pl = ctx.planes_from_pixels(r2.pix)
-            lin2 = ctx.linearization(ctx.transformation_fwd(pl))
+            pl = cx.planes_from_pixels(r2.pix)
+            lin2 = cx.linearization(cx.transformation_fwd(pl))
             del pl
-            cr = coder_record(ctx, torch, dwt_amd, lin2, r2.W, r2.H, r2.C, r2.B, r2.stride, dev, reps=1)
+            cr = coder_record(cx, torch, dwt_amd, lin2, r2.W, r2.H, r2.C, r2.B, r2.stride, dev, reps=1)
             del lin2
             extras[name] = {
-                "workload": f"{r2.W}x{r2.H}x{r2.C}, {r2.B} frames per step, 3 steps ({CONFIG_OF[name]})",
-                "value": round(3 * r2.B * r2.W * r2.H / t2 / 1e6, 1), "unit": "Mpixels/s",
-                "Msamples_per_s": round(3 * r2.B * r2.W * r2.H * r2.C / t2 / 1e6, 1),
-                "ms_per_step": round(t2 / 3 * 1e3, 3), "bytes_per_frame": int(l2.sum().item() / r2.B),
+                "workload": f"{r2.W}x{r2.H}x{r2.C}, {r2.B} frames per step, {XS} steps ({CONFIG_OF[name]})",
+                "value": round(XS * r2.B * r2.W * r2.H / t2 / 1e6, 1), "unit": "Mpixels/s",
+                "Msamples_per_s": round(XS * r2.B * r2.W * r2.H * r2.C / t2 / 1e6, 1),
+                "ms_per_step": round(t2 / XS * 1e3, 3), "bytes_per_frame": int(l2.sum().item() / r2.B),
                 "roundtrip_lossless": ok2, "stream0_matches_reference_golden": g2,
                 "coder_encode_frac_of_hbm_peak": cr["encode"]["frac_of_hbm_peak"],
                 "coder_decode_frac_of_hbm_peak": cr["decode"]["frac_of_hbm_peak"],
                 "coder_encode_ms": cr["encode"]["ms_per_step"], "coder_decode_ms": cr["decode"]["ms_per_step"],
-                "sidecar_index": with_index(r2.out[0], ctx.stream_lengths(r2.info[0]), r2.W, r2.H, r2.C, r2.B, r2.dec, r2.pix),
+                "sidecar_index": with_index(cx, r2.out[0], cx.stream_lengths(r2.info[0]), r2.W, r2.H, r2.C, r2.B, r2.dec, r2.pix),
             }
             del r2, s2, d2
+            cx.close()
+            del cx
         result["workloads"] = extras
 
     if rank == 0:
