@@ -4,6 +4,9 @@
  * Same argv, "-" for stdin/stdout, exit codes (0 ok, 1 on bad args / unreadable
  * input / size out of range / unwritable output), stderr statistics lines and
  * .dwt bytes.  The transform and the coder run on the GPU through libdwtx.
+ *
+ * Beyond the reference: with DWTX_WRITE_INDEX set in the environment the stream just written is walked once by the
+ * decoder and its sidecar index (include/dwtx.h dwtx_index) is left in "output.dwt.idx", for later decodes to find.
  */
 #include "../../../include/dwtx.h"
 #include "pnm_io.h"
@@ -51,6 +54,32 @@ int main(int argc, char **argv)
 		fprintf(stderr, "could not write to file \"%s\"\n", argv[2]);   /* bytes.h:80 */
 	fclose(f);
 	fprintf(stderr, "%d bits (%d KiB) encoded\n", st.total_bits, st.kib);   /* encode.c:230 */
+	if (getenv("DWTX_WRITE_INDEX") && strcmp(argv[2], "-")) {
+		/* the index is what a decode of the stream finds out (a stream cut by CAPACITY has none) */
+		dwtx_index *ix = (dwtx_index *)calloc(1, sizeof(dwtx_index));
+		const size_t dstride = (len + 64 + 7) / 8 * 8;
+		uint8_t *padded = (uint8_t *)calloc(dstride, 1);
+		uint8_t *back = (uint8_t *)malloc((size_t)W * H * C);
+		memcpy(padded, out, len);
+		int ow, oh, oc;
+		dwtx_decode_info info;
+		dwtx_ctx_set_index(ctx, NULL, ix);
+		if (!dwtx_decode_images_info(ctx, padded, dstride, &len, 1, -1, back, (size_t)W * H * C, &ow, &oh, &oc, &info) && ix->nsegs > 0) {
+			char *iname = (char *)malloc(strlen(argv[2]) + 5);
+			sprintf(iname, "%s.idx", argv[2]);
+			FILE *fo = fopen(iname, "wb");
+			if (fo) {
+				fwrite(ix, 1, sizeof(dwtx_index) - sizeof(ix->seg), fo);
+				fwrite(ix->seg, sizeof(dwtx_seg_index), (size_t)ix->nsegs, fo);
+				fclose(fo);
+			}
+			free(iname);
+		}
+		dwtx_ctx_set_index(ctx, NULL, NULL);
+		free(back);
+		free(padded);
+		free(ix);
+	}
 	dwtx_ctx_destroy(ctx);
 	free(out);
 	free(pix);

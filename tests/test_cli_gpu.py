@@ -283,6 +283,15 @@ def test_decode_leaves_and_takes_a_sidecar_index(tmp_path):
     assert not os.path.exists(dwt + ".idx")
     decode(DWTX_WRITE_INDEX="1")
     idx = open(dwt + ".idx", "rb").read()
+    # `encode` can leave the same file behind (it walks the stream it has just written once)
+    dwt2 = str(tmp_path / "b.dwt")
+    r = subprocess.run([ENC, SMPTE, dwt2], capture_output=True, timeout=300, env=dict(os.environ, DWTX_WRITE_INDEX="1"))
+    assert r.returncode == 0 and open(dwt2, "rb").read() == open(dwt, "rb").read()
+    assert open(dwt2 + ".idx", "rb").read() == idx
+    r = subprocess.run([ENC, SMPTE, dwt2, "4096"], capture_output=True, timeout=300, env=dict(os.environ, DWTX_WRITE_INDEX="1"))
+    os.remove(dwt2 + ".idx")
+    r = subprocess.run([ENC, SMPTE, dwt2, "4096"], capture_output=True, timeout=300, env=dict(os.environ, DWTX_WRITE_INDEX="1"))
+    assert r.returncode == 0 and not os.path.exists(dwt2 + ".idx")   # a stream cut by CAPACITY has no index
     assert idx[:4] == b"DWTI" and len(idx) == 32 + 32 * int.from_bytes(idx[16:20], "little")
     decode(DWTX_NO_INDEX_FALLBACK="1")            # the index is accepted (a rejected one would be an error here)
     open(dwt + ".idx", "wb").write(idx[:200] + bytes(len(idx) - 200))
