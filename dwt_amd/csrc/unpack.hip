@@ -8,8 +8,12 @@
 //
 //   k_nch       chunks of every stream that hold bytes (the tables below are laid
 //               out for the stream stride but worked on only that far).
-//   k_spec/k_link_*/k_scan_*/k_breaks  speculative 128-bit chunk parse that lets the
-//               walker jump over stitched stretches of the stream (see below).
+//   k_peek + k_clear_bitmaps  the plane counts of every stream's preamble bound how much of
+//               its symbol bitmap can be used: only that much is cleared.
+//   k_spec/k_link_*/k_scan_*  speculative 128-bit chunk parse that lets the walker jump
+//               over stitched stretches of the stream (see below): one family of
+//               recorded paths, two (even / odd start) for a part of the batch whose
+//               walk gives up on a parity-locked stretch (k_part_reset).
 //   k_tokenize  one wave per image (all lanes on the same uniform values): walks
 //               header, root image, plane counts and the segment schedule.  It
 //               touches no coefficient: per-(channel, level) counters of
@@ -22,6 +26,10 @@
 //               (one flag, sign) at (segment symbol base + symbol index).
 //               Truncated streams simply stop here; what was parsed stays valid
 //               (decode.c:204-205).
+//   k_tokenize<true> + k_segprep / k_segjoin  the same walk with one wave per SEGMENT
+//               when a sidecar index (include/dwtx.h dwtx_index: the walk's state at
+//               every segment start, recorded by the serial walk) is offered; k_segjoin
+//               checks that the segments fit together, else the serial walk runs.
 //   k_hopbits   re-parses every chunk (piece) the walker accounted for and sets
 //               its symbol bits.
 //   k_rank + k_count  per plane, descending, on per-tile COUNTS only: first pass-1
@@ -34,8 +42,8 @@
 //               significant one is refinement bit #(index - rank) -> read straight
 //               from the stream.  Written once, in two's complement
 //               (decode.c:102-117).
-// Batches run as two halves on two streams (the second also clears `symbits`
-// while the first builds its tables); see dwtx_decode_planes_ex.
+// Batches run as two to four parts on streams of their own (the second also clears
+// `symbits` while the first builds its tables); see dwtx_decode_planes_ex.
 #include "hilbert_dev.h"
 
 #include <stdlib.h>
