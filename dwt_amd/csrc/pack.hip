@@ -309,18 +309,33 @@ __device__ __forceinline__ void hist_finish(const Work &w, int plane, int tile, 
 	constexpr unsigned long long ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 	unsigned long long Ra = 0, Rb = 0;
 	unsigned mx = 0;
+	if (ok == 0xffffu) {   // (uniform) a whole tile, nearly always: no per-coefficient masking
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const int v = val[i];
-		const unsigned a = (unsigned)(v < 0 ? -v : v);
-		mx |= a;
-		int t = a ? 32 - __builtin_clz(a) : 0;
-		t = (ok >> i) & 1u ? t : 16;   // past the ring's end: counted nowhere
-		const unsigned long long m = t < 16 ? ONES << (4 * t) : 0ull;
-		if (i < 8)
-			Ra += m;
-		else
-			Rb += m;
+		for (int i = 0; i < 16; ++i) {
+			const int v = val[i];
+			const unsigned a = (unsigned)(v < 0 ? -v : v);
+			mx |= a;
+			const int t = a ? 32 - __builtin_clz(a) : 0;
+			const unsigned long long m = t < 16 ? ONES << (4 * t) : 0ull;
+			if (i < 8)
+				Ra += m;
+			else
+				Rb += m;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int v = val[i];
+			const unsigned a = (unsigned)(v < 0 ? -v : v);
+			mx |= a;
+			int t = a ? 32 - __builtin_clz(a) : 0;
+			t = (ok >> i) & 1u ? t : 16;   // past the ring's end: counted nowhere
+			const unsigned long long m = t < 16 ? ONES << (4 * t) : 0ull;
+			if (i < 8)
+				Ra += m;
+			else
+				Rb += m;
+		}
 	}
 	const unsigned long long ev = (Ra & M0F) + (Rb & M0F);                 // byte b: #(t <= 2b) of this lane
 	const unsigned long long od = ((Ra >> 4) & M0F) + ((Rb >> 4) & M0F);   // byte b: #(t <= 2b+1)
