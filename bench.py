@@ -38,8 +38,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
     "gray4096": (4096, 4096, 1, 64),
-    "rgb1080p": (1920, 1080, 3, 64),
-    "rgb4096": (4096, 4096, 3, 16),
+    "rgb1080p": (1920, 1080, 3, 256),   # (configs[2] is 1024 frames: the decoder's per-image token walk hides behind batches from about 256 on)
+    "rgb4096": (4096, 4096, 3, 32),
 }
 CONFIG_OF = {
     "gray4096": "BASELINE.json configs[1] geometry",
