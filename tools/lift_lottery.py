@@ -13,7 +13,7 @@ for attempt in range(8):
     pyr = torch.empty_like(x)
     back = torch.empty_like(x)
     res = []
-    for fn in (lambda: ctx.transformation_fwd(x, pyr), lambda: ctx.transformation_inv(pyr, back)):
+    for fn in (lambda: ctx.transformation_fwd(x, pyr), lambda: ctx.transformation_inv(pyr, back), lambda: back.copy_(x)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -21,7 +21,7 @@ for attempt in range(8):
             fn()
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 10 * 1e3 / P)
-    print(f"attempt {attempt}: fwd {res[0]:.1f} inv {res[1]:.1f} us/plane  x@{x.data_ptr():#x} pyr@{pyr.data_ptr():#x}")
+    print(f"attempt {attempt}: fwd {res[0]:.1f} inv {res[1]:.1f} plain copy {res[2]:.1f} us/plane  x@{x.data_ptr():#x} pyr@{pyr.data_ptr():#x}")
     del x, pyr, back
     if attempt % 2 == 1:
         keep.append(torch.empty(int(1e9) + attempt * 12345678, dtype=torch.uint8, device="cuda"))   # shifts the next addresses
