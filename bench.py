@@ -297,7 +297,7 @@ def main():
     # the buffers at the very same virtual addresses, tools/lift_lottery.py: the physical pages behind them differ):
     # three attempts on fresh buffers, all reported; the figure is their mean (what a rocprofv3 summary of this run averages to).
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    attempts = []
+    attempts, copies = [], []
     lift_ms = None
     for attempt in range(3):
         planes = pyr = back = None
@@ -317,6 +317,13 @@ def main():
         ms = e0.elapsed_time(e1) / args.lift_reps
         attempts.append(round(ms * 1e3 / B, 2))
         lift_ms = ms if lift_ms is None else lift_ms + ms
+        # a plain copy of the same planes in the same buffers (8 B per sample): the streaming ceiling of this allocation
+        e0.record()
+        for _ in range(args.lift_reps):
+            back.copy_(planes)
+        e1.record()
+        torch.cuda.synchronize()
+        copies.append(round(e0.elapsed_time(e1) / args.lift_reps * 1e3 / B, 2))
     lift_ms /= len(attempts)
     # (the separate forward / inverse loops below run on the last attempt's buffers)
     lift_ok = bool(torch.equal(back, planes))
@@ -410,6 +417,8 @@ def main():
                 "bytes_per_sample": LIFT_BYTES_PER_SAMPLE,
                 "us_per_frame": round(lift_ms * 1e3 / B, 2),
                 "us_per_frame_attempts": attempts,
+                "plain_copy_us_per_frame_same_buffers": copies,   # 8 B per sample each; forward + inverse are two such passes plus the pyramid's 1/3
+                "vs_two_plain_copies": round(2 * sum(copies) / len(copies) / (lift_ms * 1e3 / B), 3),
                 "forward_us_per_frame": round(fwd_ms * 1e3 / B, 2),
                 "inverse_us_per_frame": round(inv_ms * 1e3 / B, 2),
             },
