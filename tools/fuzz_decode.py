@@ -1,7 +1,8 @@
 """Longer seeded sweep of the decoder against the oracle (development aid, GPU box; not part of the test suite):
 random geometries and contents, whole streams, cuts, damaged streams, in batches of mixed kinds (>= 3 streams, so
 that the one-family walk and both halves of the batch run), with and without sidecar indices (right ones, and
-the indices of other streams).   tools/fuzz_decode.py [seed] [cases]"""
+the indices of other streams).   tools/fuzz_decode.py [seed] [cases] [big]   (big: batches of 30-45 streams, which the decoder
+cuts into four parts instead of two)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +14,7 @@ from test_oracle import corrupted_blobs
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+big = len(sys.argv) > 3
 rng = np.random.default_rng(seed)
 ctx = dwt_amd.Context(0)
 t0 = time.time()
@@ -22,7 +24,7 @@ for case in range(cases):
     if case % 4 == 0:
         W = H = int(2 ** rng.integers(3, 11))
     Cn = 1 if rng.integers(0, 2) else 3
-    n = int(rng.integers(3, 9))
+    n = int(rng.integers(18, 30)) if big else int(rng.integers(3, 9))
     good = [orc.encode(orc.synth(W, H, Cn, int(rng.integers(0, 1 << 30)), int(rng.integers(0, 2))))[0] for _ in range(n)]
     blobs = list(good)
     for g in good[:3]:
