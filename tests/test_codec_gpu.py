@@ -413,3 +413,19 @@ def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, mo
     outs2 = ctx.decode(streams)
     for i in range(n):
         assert (outs2[i] == outs[i]).all()
+
+
+@pytest.mark.parametrize("parts", ["2", "3", "4"])
+def test_decode_batches_in_two_three_or_four_parts(ctx, parts, monkeypatch):
+    """A decode batch runs as parts on streams of their own (unpack.hip dwtx_decode_planes_ex; four from 24 images on):
+    whole, cut and damaged streams of one geometry, 29 of them, come out the same however the batch is cut."""
+    from test_oracle import corrupted_blobs
+
+    W, H, Cn = 120, 88, 3
+    good = [orc.encode(orc.synth(W, H, Cn, 70 + i, i & 1))[0] for i in range(17)]
+    blobs = good + [g[: len(g) * (i + 2) // 9] for i, g in enumerate(good[:6])] + corrupted_blobs(good[0], 6, 3)
+    want = [orc.decode(b) for b in blobs]
+    monkeypatch.setenv("DWTX_DECODE_PARTS", parts)
+    got = ctx.decode(blobs)
+    for w, g in zip(want, got):
+        assert (w is None and g is None) or (g is not None and g.shape == w.shape and (g == w).all())
