@@ -786,8 +786,10 @@ constexpr int ROWW = 34;             // words per staging row of one plane (31 +
 struct alignas(16) CodeLds {
 	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1] | (t-1) << 12,  first slot of plane t-1 + Z[t] - Z[t-1] };
 	                                 // more: [lane][t-1] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
-	unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 10 | plane << 12
-	unsigned rows[(MAX_PLANES - 1) * ROWW];
+	union {                          // (the token slots have left for memory before the refinement rows are gathered)
+		unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 10 | plane << 12
+		unsigned rows[(MAX_PLANES - 1) * ROWW];
+	};
 	unsigned short cum[MAX_PLANES + 2];   // the tile's histogram: #(t <= q), q = 0..16
 	unsigned gb[MAX_PLANES];         // plane p: token index of the entry's first token minus the plane's first slot; ~0: plane not coded
 	unsigned long long rb[MAX_PLANES];    // plane p: bit position of the entry's refinement bits in the staging buffer
@@ -958,6 +960,10 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	}
 
 	// ---- pass C: refinement bits (encode.c:84-93), per plane a <= 16-bit string per lane at rank (coefficients before) - Z[p+1] ----
+	wave_sync();
+	for (int i = lane; i < (MAX_PLANES - 1) * ROWW; i += 64)
+		L.rows[i] = 0u;
+	wave_sync();
 	for (int p = P - 2; p >= 0; --p) {
 		const int refs = nvalid - (int)L.cum[p + 1];
 		if (refs <= 0 || L.ent[p] < 0)
@@ -1003,17 +1009,16 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	}
 }
 
-__global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
+// Two kernels: planes of up to 8 bit planes — every 8-bit picture — take the variant with 32-bit count registers,
+// which alone needs 94 vector registers where the two variants in one kernel needed 126: five waves per SIMD instead
+// of four (its LDS fits five workgroups per CU since the refinement rows share the token slots' words).  The wide
+// variant runs a small grid that strides over the tiles, so that launching it for nothing costs nothing.
+template <bool WIDE>
+__device__ __forceinline__ void code_one(const PackGeom &g, const int *__restrict__ lin, const Work &w, CodeLds &L, int tile, int plane, int lane)
 {
-	__shared__ CodeLds lds[4];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int tile = blockIdx.x * 4 + wv;
-	const int plane = blockIdx.y;
-	if (tile >= w.NT)
-		return;   // whole wave; nothing below synchronises across waves
-	CodeLds &L = lds[wv];
 	const int img = plane / g.C, c = plane - img * g.C;
 	const ImgInfo &I = w.info[img];
+	{
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
@@ -1047,15 +1052,35 @@ __global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict_
 			my_tokbase = w.ent_tokbase[img * (w.ES + 1) + my_ent];
 		}
 	}
-	for (int i = lane; i < (MAX_PLANES - 1) * ROWW; i += 64)
-		L.rows[i] = 0u;
-	if (P <= 8) {
+	if (!WIDE) {
 		if (nvalid == TILE)
 			code_tile<8, true>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
 		else
 			code_tile<8, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
 	} else {
 		code_tile<16, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+	}
+	}
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
+{
+	__shared__ CodeLds lds[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int plane = blockIdx.y;
+	const int img = plane / g.C, c = plane - img * g.C;
+	if ((w.info[img].planes[c] > 8) != WIDE)
+		return;   // (uniform over the workgroup) the other kernel's plane
+	if (!WIDE) {
+		const int tile = blockIdx.x * 4 + wv;
+		if (tile < w.NT)   // whole wave; nothing below synchronises across waves
+			code_one<false>(g, lin, w, lds[wv], tile, plane, lane);
+	} else {
+		for (int tile = blockIdx.x * 4 + wv; tile < w.NT; tile += gridDim.x * 4) {
+			code_one<true>(g, lin, w, lds[wv], tile, plane, lane);
+			wave_sync();   // the wave's next tile reuses its LDS
+		}
 	}
 }
 
@@ -2156,7 +2181,8 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_stage_zero, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
-	hipLaunchKernelGGL(k_code, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_code<false>, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
+	hipLaunchKernelGGL(k_code<true>, dim3(dwtx_cdiv(NT, 4) < 64 ? dwtx_cdiv(NT, 4) : 64, nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
 	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
