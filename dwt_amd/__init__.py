@@ -73,6 +73,13 @@ class Context:
         except Exception:
             pass
 
+    def set_option(self, name, value=1):
+        """Diagnostic switch of the context (enum dwtx_option in include/dwtx.h; tests and tools only)."""
+        _check(self.lib.dwtx_ctx_set_option(self.h, _lib.OPTIONS[name], int(value)), "dwtx_ctx_set_option")
+
+    def get_option(self, name):
+        return self.lib.dwtx_ctx_get_option(self.h, _lib.OPTIONS[name])
+
     def set_index(self, offered=None, wanted=0):
         """Sidecar indices for the decode calls that follow (dwtx_ctx_set_index): `offered` is an array of Index
         made by new_indices()/an earlier decode (entry i goes with image i of a call), `wanted` the number of

@@ -66,6 +66,11 @@ class Stats(C.Structure):
     ]
 
 
+# enum dwtx_option (include/dwtx.h): diagnostic switches of a context
+OPTIONS = {name: i for i, name in enumerate((
+    "exact_orders", "no_square_tiles", "part_images", "one_stream", "decode_parts", "two_families", "no_second_walk",
+    "no_index", "no_index_fallback", "no_capacity_cut"))}
+
 # name -> (restype, argtypes); must list every symbol include/dwtx.h declares
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
@@ -76,6 +81,8 @@ SYMBOLS = {
     "dwtx_sync": (_i, [_vp]),
     "dwtx_ctx_set_index": (_i, [_vp, _vp, _vp]),
     "dwtx_stream": (_vp, [_vp]),
+    "dwtx_ctx_set_option": (_i, [_vp, _i, C.c_long]),
+    "dwtx_ctx_get_option": (C.c_long, [_vp, _i]),
     "dwtx_malloc": (_vp, [_vp, _sz]),
     "dwtx_free": (None, [_vp, _vp]),
     "dwtx_host_alloc": (_vp, [_vp, _sz]),

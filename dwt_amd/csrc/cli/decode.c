@@ -79,6 +79,11 @@ int main(int argc, char **argv)
 			ix_out = (dwtx_index *)calloc(1, sizeof(dwtx_index));
 	}
 	dwtx_ctx_set_index(ctx, ix_in, ix_out);
+	/* debugging aids of this tool (the library reads no environment): ignore the sidecar index / refuse to fall back from one */
+	if (getenv("DWTX_NO_INDEX"))
+		dwtx_ctx_set_option(ctx, DWTX_OPT_NO_INDEX, 1);
+	if (getenv("DWTX_NO_INDEX_FALLBACK"))
+		dwtx_ctx_set_option(ctx, DWTX_OPT_NO_INDEX_FALLBACK, 1);
 	int ow, oh, oc;
 	dwtx_decode_info info;
 	int rc = dwtx_decode_images_info(ctx, padded, stride, &len, 1, pixels_max, pix, (size_t)W * H * C, &ow, &oh, &oc, &info);

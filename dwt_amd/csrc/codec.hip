@@ -24,6 +24,7 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 {
 	if (!ctx || !dev_pix || !dev_out || !dev_info || (C != 1 && C != 3) || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
 	const size_t bytes = sizeof(int) * (size_t)W * H * C * n;
 	int *a = (int *)dwtx_scratch(ctx, SLOT_CD_A, bytes);
@@ -41,7 +42,7 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 			return rc;
 	}
 	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
-	const unsigned sq = getenv("DWTX_NO_SQUARE_TILES") ? 0u : dwtx_square_levels(W, H);
+	const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
 	if ((rc = dwtx_linearization_ex(ctx, a, b, W, H, n * C, sq)))
 		return rc;
 	return dwtx_encode_planes_ex(ctx, a, b, sq, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
@@ -55,6 +56,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 {
 	if (!ctx || !dev_streams || !dev_lens || !dev_pix || !host_info || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
 	dwtx_geom g;
 	int rc = dwtx_geometry(&g, W, H);
@@ -139,13 +141,13 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 // stream, two device staging buffers each way): device memory stays bounded for any n, and with
 // page-locked host buffers (dwtx_host_alloc) the PCIe transfers hide behind the kernels.
 
-static int part_size(int W, int H, int C, int n)
+static int part_size(const dwtx_ctx *ctx, int W, int H, int C, int n)
 {
 	const size_t samples = (size_t)W * H * C;
 	size_t p = ((size_t)64 << 20) / (samples ? samples : 1);   // about 64 M samples per part (16 frames of 4096x4096 gray)
 	p = p < 4 ? 4 : p > 256 ? 256 : p;
-	if (const char *env = getenv("DWTX_PART_IMAGES"))   // test hook: force small parts
-		p = atoi(env) > 0 ? (size_t)atoi(env) : p;
+	if (ctx->opt[DWTX_OPT_PART_IMAGES] > 0)   // test hook: force small parts
+		p = (size_t)ctx->opt[DWTX_OPT_PART_IMAGES];
 	return (size_t)n < p ? n : (int)p;
 }
 
@@ -161,8 +163,9 @@ extern "C" int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *pix, int W, int 
 {
 	if (!ctx || !pix || !out || !out_lens || (out_stride & 7) || n < 1 || (C != 1 && C != 3))
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
-	const int P = part_size(W, H, C, n), parts = (n + P - 1) / P;
+	const int P = part_size(ctx, W, H, C, n), parts = (n + P - 1) / P;
 	const size_t img_bytes = (size_t)W * H * C;
 	int rc = dwtx_need_copy_stream(ctx);
 	if (rc)
@@ -266,6 +269,7 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 {
 	if (!ctx || !streams || !lens || !pix || !outW || !outH || !outC || n < 1 || (stream_stride & 7))
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	// decode.c:142-159: geometry comes from the first stream's header; all streams of a batch share it
 	if (lens[0] < 6 || streams[0] != 'W' || (streams[1] != '5' && streams[1] != '6'))
 		return DWTX_ERR_ARG;
@@ -285,7 +289,7 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 		while (levels_max > 0 && g.pixels[levels_max] > pixels_max)
 			--levels_max;
 	}
-	const int P = part_size(W, H, C, n), parts = (n + P - 1) / P;
+	const int P = part_size(ctx, W, H, C, n), parts = (n + P - 1) / P;
 	const size_t img_bytes = (size_t)W * H * C;
 	int rc = dwtx_need_copy_stream(ctx);
 	if (rc)
@@ -347,7 +351,12 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 			outC[i0 + i] = C;
 			if (I.status) {
 				outW[i0 + i] = outH[i0 + i] = 0;
-				rc = n == 1 ? DWTX_ERR_IO : rc;   // decode.c:181,185: unreadable root/planes -> exit 1
+				if (n == 1 && I.status == 2) {   // refused, not unreadable: the caller is told why
+					dwtx_set_error("the stream claims more than 16 bit planes: damaged, refused (the reference would decode garbage)");
+					rc = DWTX_ERR_ARG;
+				} else {
+					rc = n == 1 ? DWTX_ERR_IO : rc;   // decode.c:181,185: unreadable root/planes -> exit 1
+				}
 				continue;
 			}
 			const int lo = I.level + 1;
@@ -360,7 +369,7 @@ extern "C" int dwtx_decode_images_info(dwtx_ctx *ctx, const uint8_t *streams, si
 			e = hipEventRecord(ev_out[slot], cs);
 	}
 	const int s = sync_all(ctx);
-	if (infos && e == hipSuccess && !s && (rc == DWTX_OK || rc == DWTX_ERR_IO))
+	if (infos && e == hipSuccess && !s && (rc == DWTX_OK || rc == DWTX_ERR_IO || rc == DWTX_ERR_ARG))
 		memcpy(infos, info, sizeof(dwtx_decode_info) * (size_t)n);
 	free(hl);
 	free(info);

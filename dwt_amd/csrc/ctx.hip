@@ -62,6 +62,44 @@ extern "C" int dwtx_ctx_create_on_stream(int device, void *stream, dwtx_ctx **ou
 	return ctx_create(device, stream, false, out);
 }
 
+// Makes the context's device current for the calling thread (the HIP runtime keeps one current device per thread;
+// streams, events and allocations belong to the device they were made on).
+int dwtx_enter(dwtx_ctx *c)
+{
+	if (!c)
+		return DWTX_ERR_ARG;
+	int cur = -1;
+	if (hipGetDevice(&cur) == hipSuccess && cur == c->device)
+		return DWTX_OK;
+	DWTX_HIP(hipSetDevice(c->device));
+	return DWTX_OK;
+}
+
+#ifdef DWTX_DEBUG_HOOKS
+int dwtx_debug_check_device(dwtx_ctx *c, const char *file, int line)
+{
+	int cur = -1;
+	if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
+		dwtx_set_error("%s:%d kernels launched with device %d current, the context lives on device %d", file, line, cur, c->device);
+		return DWTX_ERR_DEVICE;
+	}
+	return DWTX_OK;
+}
+#endif
+
+extern "C" int dwtx_ctx_set_option(dwtx_ctx *c, int option, long value)
+{
+	if (!c || option < 0 || option >= DWTX_OPT_COUNT)
+		return DWTX_ERR_ARG;
+	c->opt[option] = value;
+	return DWTX_OK;
+}
+
+extern "C" long dwtx_ctx_get_option(dwtx_ctx *c, int option)
+{
+	return c && option >= 0 && option < DWTX_OPT_COUNT ? c->opt[option] : 0;
+}
+
 extern "C" int dwtx_ctx_set_index(dwtx_ctx *c, const dwtx_index *in, dwtx_index *out)
 {
 	if (!c)
@@ -107,6 +145,7 @@ int dwtx_need_copy_stream(dwtx_ctx *c)
 {
 	if (c->have_copy)
 		return DWTX_OK;
+	DWTX_ENTER(c);
 	DWTX_HIP(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
 	for (int i = 0; i < 6; ++i)
 		DWTX_HIP(hipEventCreateWithFlags(&c->cev[i], hipEventDisableTiming));
@@ -119,7 +158,8 @@ int dwtx_need_copy_stream(dwtx_ctx *c)
 extern "C" void *dwtx_host_alloc(dwtx_ctx *c, size_t bytes)
 {
 	void *p = nullptr;
-	(void)hipSetDevice(c->device);
+	if (dwtx_enter(c))
+		return nullptr;
 	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
 	if (e != hipSuccess) {
 		dwtx_set_error("hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
@@ -130,7 +170,7 @@ extern "C" void *dwtx_host_alloc(dwtx_ctx *c, size_t bytes)
 
 extern "C" void dwtx_host_free(dwtx_ctx *c, void *host)
 {
-	if (!host)
+	if (!host || dwtx_enter(c))
 		return;
 	(void)hipStreamSynchronize(c->stream);
 	if (c->have_copy)
@@ -140,6 +180,7 @@ extern "C" void dwtx_host_free(dwtx_ctx *c, void *host)
 
 extern "C" int dwtx_sync(dwtx_ctx *c)
 {
+	DWTX_ENTER(c);
 	DWTX_HIP(hipStreamSynchronize(c->stream));
 	return DWTX_OK;
 }
@@ -152,7 +193,8 @@ extern "C" void *dwtx_stream(dwtx_ctx *c)
 extern "C" void *dwtx_malloc(dwtx_ctx *c, size_t bytes)
 {
 	void *p = nullptr;
-	(void)hipSetDevice(c->device);
+	if (dwtx_enter(c))
+		return nullptr;
 	hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
 	if (e != hipSuccess) {
 		dwtx_set_error("hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
@@ -163,7 +205,7 @@ extern "C" void *dwtx_malloc(dwtx_ctx *c, size_t bytes)
 
 extern "C" void dwtx_free(dwtx_ctx *c, void *dev)
 {
-	if (!dev)
+	if (!dev || dwtx_enter(c))
 		return;
 	(void)hipStreamSynchronize(c->stream);
 	(void)hipFree(dev);
@@ -171,6 +213,7 @@ extern "C" void dwtx_free(dwtx_ctx *c, void *dev)
 
 extern "C" int dwtx_upload(dwtx_ctx *c, void *dev, const void *host, size_t bytes)
 {
+	DWTX_ENTER(c);
 	DWTX_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
 	DWTX_HIP(hipStreamSynchronize(c->stream));
 	return DWTX_OK;
@@ -178,6 +221,7 @@ extern "C" int dwtx_upload(dwtx_ctx *c, void *dev, const void *host, size_t byte
 
 extern "C" int dwtx_download(dwtx_ctx *c, void *host, const void *dev, size_t bytes)
 {
+	DWTX_ENTER(c);
 	DWTX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
 	DWTX_HIP(hipStreamSynchronize(c->stream));
 	return DWTX_OK;
@@ -189,6 +233,8 @@ void *dwtx_scratch(dwtx_ctx *c, int slot, size_t bytes)
 		return nullptr;
 	if (c->scratch_bytes[slot] >= bytes && c->scratch[slot])
 		return c->scratch[slot];
+	if (dwtx_enter(c))   // the allocation below belongs to the context's device, whatever the thread had current
+		return nullptr;
 	// kernels still in flight may use the old buffer
 	(void)hipStreamSynchronize(c->stream);
 	if (c->scratch[slot])

@@ -29,7 +29,23 @@ struct dwtx_ctx {
 	const dwtx_index *index_in;   // dwtx_ctx_set_index: sidecar indices offered to / asked from the decode calls
 	dwtx_index *index_out;
 	size_t index_base;            // entry of the current call's first image (the host pipeline decodes a batch in parts)
+	long opt[DWTX_OPT_COUNT];     // dwtx_ctx_set_option: diagnostic switches (tests, tools), all 0 by default
 };
+
+// Every entry point that allocates, launches or copies makes the context's device the calling thread's current
+// one first: a host that drives several contexts (one per GPU) from one thread gets its kernels and scratch on the
+// right device.  On a single-GPU process it is one hipGetDevice().
+int dwtx_enter(dwtx_ctx *ctx);
+#define DWTX_ENTER(ctx)              \
+	do {                             \
+		const int rc_ = dwtx_enter(ctx); \
+		if (rc_)                     \
+			return rc_;              \
+	} while (0)
+#ifdef DWTX_DEBUG_HOOKS
+// debug builds: every kernel-launching function checks that it runs on its context's device
+int dwtx_debug_check_device(dwtx_ctx *ctx, const char *file, int line);
+#endif
 
 void dwtx_free_plans(dwtx_ctx *ctx);
 int dwtx_need_copy_stream(dwtx_ctx *ctx);   // creates ctx->copy / ctx->cev on first use
@@ -47,7 +63,16 @@ void *dwtx_scratch(dwtx_ctx *ctx, int slot, size_t bytes);
 		}                                                                       \
 	} while (0)
 
+#ifdef DWTX_DEBUG_HOOKS
+#define DWTX_LAUNCH_CHECK()                                            \
+	do {                                                               \
+		if (dwtx_debug_check_device(ctx, __FILE__, __LINE__))          \
+			return DWTX_ERR_DEVICE;                                    \
+		DWTX_HIP(hipGetLastError());                                   \
+	} while (0)
+#else
 #define DWTX_LAUNCH_CHECK() DWTX_HIP(hipGetLastError())
+#endif
 
 static inline int dwtx_cdiv(int a, int b) { return (a + b - 1) / b; }
 

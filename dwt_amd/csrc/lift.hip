@@ -982,6 +982,7 @@ extern "C" int dwtx_synth_pixels(dwtx_ctx *ctx, uint8_t *pix, int W, int H, int 
 {
 	if (!ctx || !pix || W < 1 || H < 1 || (C != 1 && C != 3) || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	const long total = (long)W * H * C * n;
 	const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
 	hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(256), 0, ctx->stream, pix, W, H, C, total, seed0, kind);
@@ -993,6 +994,7 @@ extern "C" int dwtx_planes_from_pixels(dwtx_ctx *ctx, int32_t *planes, const uin
 {
 	if (!ctx || !planes || !pix || W < 1 || H < 1 || (C != 1 && C != 3) || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	const long npix = (long)W * H, total = npix * n;
 	const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
 	hipLaunchKernelGGL(k_planes_from_pixels, dim3(blocks), dim3(256), 0, ctx->stream, planes, pix, npix, C, total);
@@ -1004,6 +1006,7 @@ extern "C" int dwtx_pixels_from_planes(dwtx_ctx *ctx, uint8_t *pix, const int32_
 {
 	if (!ctx || !planes || !pix || W < 1 || H < 1 || (C != 1 && C != 3) || n < 1)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	const long npix = (long)W * H, total = npix * n;
 	const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
 	hipLaunchKernelGGL(k_pixels_from_planes, dim3(blocks), dim3(256), 0, ctx->stream, pix, planes, npix, C, total);
@@ -1031,6 +1034,7 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 {
 	if (!ctx || !out || (!in && !in8) || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	int ws[DWTX_MAX_LEVELS + 2], hs[DWTX_MAX_LEVELS + 2];
 	const int T = lift_steps(W, H, ws, hs);
 	int *tmp[2] = { nullptr, nullptr };
@@ -1165,6 +1169,7 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 {
 	if (!ctx || (!out && !out8) || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	int ws[DWTX_MAX_LEVELS + 2], hs[DWTX_MAX_LEVELS + 2];
 	const int T = lift_steps(W, H, ws, hs);
 	int *tmp[2] = { nullptr, nullptr };

@@ -379,6 +379,7 @@ int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	dwtx_linplan *p;
 	int rc = get_plan(ctx, W, H, &p);
 	if (rc)
@@ -408,6 +409,7 @@ int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, cons
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || (C != 1 && C != 3) || n < 1 || n * C > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	dwtx_linplan *p;
 	int rc = get_plan(ctx, W, H, &p);
 	if (rc)

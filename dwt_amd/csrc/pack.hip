@@ -1946,9 +1946,10 @@ __global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, lon
 	long last = (long)((w.stream_bits[img] + 31) >> 5) + 4;
 	last = last < out_words ? last : out_words;
 	unsigned *base = out + img * out_words;
+	const bool vec = ((uintptr_t)base & 15) == 0;   // (uniform) the stream's base is only word-aligned by contract: 16-byte stores when it allows them
 	for (long i = ((first & ~3l) >> 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < last; i += (long)gridDim.x * blockDim.x) {
 		unsigned *dst = base + i * 4;
-		if (i * 4 >= first && i * 4 + 4 <= last) {
+		if (vec && i * 4 >= first && i * 4 + 4 <= last) {
 			*reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
 		} else {
 			for (int k = 0; k < 4; ++k)
@@ -2043,6 +2044,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 {
 	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
 	if (sq_levels && (!pyr || (sq_levels & ~dwtx_square_levels(W, H)) || ((uintptr_t)pyr & 15)))
 		return DWTX_ERR_ARG;
@@ -2111,7 +2113,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.brk_tok = (unsigned *)(small + o_bt);
 		w.segidx = (int *)(small + o_sx);
 		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
-		if (getenv("DWTX_FORCE_EXACT_ORDERS"))   // test hook: take the hierarchical 32-state pass for every image
+		if (ctx->opt[DWTX_OPT_EXACT_ORDERS])   // test hook: take the hierarchical 32-state pass for every image
 			DWTX_HIP(hipMemsetAsync(small + o_slow, 1, sizeof(int) * n, ctx->stream));
 
 		off = 0;

@@ -74,7 +74,7 @@ struct UnpackGeom {
 };
 
 struct DecInfo {
-	int status;            // 0 ok, 1 = header / root image / plane counts unreadable (decode.c exits 1)
+	int status;            // 0 ok, 1 = header / root image / plane counts unreadable (decode.c exits 1), 2 = more than MAX_PLANES bit planes
 	int W, H, C;
 	int levels;
 	int planes[3];
@@ -1032,14 +1032,15 @@ __global__ __launch_bounds__(256) void k_part_reset(DWork h, int cnt)
 }
 
 // decode.c:142-159 header, decode.c:119-134 root image (channel c's coefficients go to root + c * root_stride if
-// root is given), decode.c:183-186 plane counts.  false: unreadable (decode.c exits 1), or more planes than this
-// decoder handles.
-__device__ bool read_preamble(BitReader &br, const UnpackGeom &g, const unsigned char *s8, unsigned long long len, long stream_stride,
+// root is given), decode.c:183-186 plane counts.  0: read; 1: unreadable (decode.c exits 1); 2: a plane count above
+// MAX_PLANES — only damage can produce one (8-bit sources stay below 12): refused, where the reference goes on and
+// decodes garbage (decode.c:183-186 accepts any get_vli() value) — the one documented difference, DESIGN.md section 7.
+__device__ int read_preamble(BitReader &br, const UnpackGeom &g, const unsigned char *s8, unsigned long long len, long stream_stride,
 	int &order, int (&planes)[3], int *root, long root_stride)
 {
 	if (len < 6 || s8[0] != 'W' || s8[1] != (g.C == 3 ? '6' : '5') ||
 		(s8[2] | (s8[3] << 8)) + 1 != g.W || (s8[4] | (s8[5] << 8)) + 1 != g.H)
-		return false;
+		return 1;
 	br.w = (const unsigned long long *)s8;
 	br.n64 = stream_stride >> 3;
 	br.end_bits = len * 8;
@@ -1048,25 +1049,27 @@ __device__ bool read_preamble(BitReader &br, const UnpackGeom &g, const unsigned
 	for (int c = 0; c < g.C; ++c) {
 		unsigned cnt;
 		if (br.vli_any(order, cnt))
-			return false;
+			return 1;
 		if (cnt)
 			for (int i = 0; i < g.pixels[0]; ++i) {
 				unsigned v, neg = 0;
 				if (!br.read_any(cnt, v))
-					return false;
+					return 1;
 				if (v && !br.read(1, neg))
-					return false;
+					return 1;
 				if (root)
 					root[c * root_stride + i] = neg ? -(int)v : (int)v;
 			}
 	}
 	for (int c = 0; c < g.C; ++c) {
 		unsigned p;
-		if (br.vli_any(order, p) || p > MAX_PLANES)
-			return false;
+		if (br.vli_any(order, p))
+			return 1;
+		if (p > MAX_PLANES)
+			return 2;
 		planes[c] = (int)p;
 	}
-	return true;
+	return 0;
 }
 
 // How much of its symbol bitmap an image can use follows from its plane counts: every segment owns ceil32(ring
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_peek(UnpackGeom g, const unsigned char *
 	BitReader br;
 	int order, planes[3] = { 0, 0, 0 };
 	unsigned long long words = 0;
-	if (read_preamble(br, g, s8, len, stream_stride, order, planes, nullptr, 0)) {
+	if (!read_preamble(br, g, s8, len, stream_stride, order, planes, nullptr, 0)) {
 		unsigned long long per = 0;
 		for (int l = 0; l < g.levels; ++l)
 			per += ((unsigned long long)(g.pixels[l + 1] - g.pixels[l]) + 31) & ~31ull;
@@ -1202,8 +1205,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	SegIndex *idx = w.idx + (long)img * MAX_SEGS;
 	if (!SEG) {
 		info_begin(I, g);
-		if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
+		if (const int bad = read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride)) {
+			I.status = bad;
 			return;
+		}
 		for (int c = 0; c < g.C; ++c) {
 			I.planes[c] = planes[c];
 			pmax = planes[c] > pmax ? planes[c] : pmax;
@@ -1473,8 +1478,12 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	if (SEG) {
 		const unsigned d = idx[seg_k].desc;
 		const int c = (int)(d & 15u), l = (int)((d >> 4) & 15u), p = (int)(d >> 8) - 1;
-		const bool sane = c < g.C && l < g.levels && p < MAX_PLANES && (unsigned long long)idx[seg_k].n1 <= (unsigned long long)(g.pixels[l + 1] - g.pixels[l]) &&
-			idx[seg_k].sym_base + (unsigned long long)(g.pixels[l + 1] - g.pixels[l]) + 32ull <= (unsigned long long)w.BW * 16ull;
+		// (an index is untrusted input: the bounds are compared without sums that could wrap, and an entry order the
+		// serial walk can only reach on a damaged stream — 32 and more — sends the image to the serial walk)
+		const unsigned long long ring = (unsigned long long)(g.pixels[l < g.levels ? l + 1 : 1] - g.pixels[l < g.levels ? l : 0]);
+		const unsigned long long sym_cap = (unsigned long long)w.BW * 16ull;
+		const bool sane = c < g.C && l < g.levels && p < MAX_PLANES && (unsigned long long)idx[seg_k].n1 <= ring && idx[seg_k].order <= 31u &&
+			ring + 32ull <= sym_cap && idx[seg_k].sym_base <= sym_cap - ring - 32ull;
 		const bool went = sane && segment(c, l, p);
 		bm.flush();
 		SegResult r;
@@ -1528,7 +1537,7 @@ __global__ __launch_bounds__(64) void k_segprep(DWork w, const unsigned long lon
 	unsigned long long at = 0;
 	for (int k = 0; good && k < K; ++k) {
 		const unsigned long long b = idx[k].bit, nb = k + 1 < K ? idx[k + 1].bit : end_bits;
-		good = b <= nb && nb <= end_bits;
+		good = b <= nb && nb <= end_bits && idx[k].sym_base < (unsigned long long)w.BW * 16ull && idx[k].order <= 31u;
 		slot[k] = (unsigned)at;
 		at += 8ull + ((nb - b) >> (CH_LOG2 + 3));
 	}
@@ -1556,8 +1565,10 @@ __global__ __launch_bounds__(64) void k_segjoin(UnpackGeom g, DWork w, const uns
 	const unsigned long long len = lens[img] < (unsigned long long)stream_stride ? lens[img] : (unsigned long long)stream_stride;
 	BitReader br;
 	int order = 0, planes[3] = { 0, 0, 0 };
-	if (!read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride))
-		return;   // unreadable: status 1, as from the serial walk
+	if (const int bad = read_preamble(br, g, s8, len, stream_stride, order, planes, lin + (long)img * g.C * g.lin_stride, g.lin_stride)) {
+		I.status = bad;   // as from the serial walk
+		return;
+	}
 	int pmax = 0;
 	for (int c = 0; c < g.C; ++c) {
 		I.planes[c] = planes[c];
@@ -2046,6 +2057,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	if (!ctx || !lin || !streams || !dev_lens || !host_info || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 ||
 		(stream_stride & 7) || stream_stride < 64)
 		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
 	UnpackGeom g;
 	{
@@ -2069,7 +2081,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 			g.side[l] = l < g.levels ? gg.lengths[l + 1] : 0;
 	}
 	// the levels that are full power-of-two squares can go straight into the pyramid (k_apply_all)
-	const unsigned sq_all = pyr && !((uintptr_t)pyr & 15) && !getenv("DWTX_NO_SQUARE_TILES") ? dwtx_square_levels(W, H) : 0u;
+	const unsigned sq_all = pyr && !((uintptr_t)pyr & 15) && !ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? dwtx_square_levels(W, H) : 0u;
 	constexpr int MAX_PARTS = 4;
 	unsigned part_mask[MAX_PARTS] = { 0u, 0u, 0u, 0u };
 	int part_first[MAX_PARTS + 1] = { 0, 0, 0, 0, 0 };   // images [part_first[k], part_first[k+1]) are part k
@@ -2275,14 +2287,14 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
 	// (a test hook: it is the path a walk that gave up falls back to).
 	// One or two images leave most of the chip idle anyway: both families then, for the shorter walk.
-	const int fam0 = n <= 2 || getenv("DWTX_TWO_FAMILIES") ? FAM : 1;
+	const int fam0 = n <= 2 || ctx->opt[DWTX_OPT_TWO_FAMILIES] ? FAM : 1;
 	// Sidecar indices (dwtx_ctx_set_index): a part of the batch whose images all come with a plausible index is
 	// walked segment-parallel; k_segjoin proves the index on the way or hands the part back to the serial walk.
 	const dwtx_index *ix_in = ctx->index_in ? ctx->index_in + ctx->index_base : nullptr;
 	dwtx_index *ix_out = ctx->index_out ? ctx->index_out + ctx->index_base : nullptr;
 	static_assert(sizeof(dwtx_seg_index) == sizeof(SegIndex) && DWTX_INDEX_MAX_SEGS == MAX_SEGS, "SegIndex is the device image of dwtx_seg_index");
 	auto indexed = [&](int i0, int cnt) -> bool {
-		if (!ix_in || g.levels_max < g.levels || getenv("DWTX_NO_INDEX"))
+		if (!ix_in || g.levels_max < g.levels || ctx->opt[DWTX_OPT_NO_INDEX])
 			return false;
 		for (int i = i0; i < i0 + cnt; ++i)
 			if (ix_in[i].magic != DWTX_INDEX_MAGIC || ix_in[i].W != W || ix_in[i].H != H || ix_in[i].C != C || ix_in[i].nsegs <= 0 ||
@@ -2343,8 +2355,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		};
 		int rc2;
 		if (part_indexed[part_of(i0)] && gave_up()) {
-			if (getenv("DWTX_NO_INDEX_FALLBACK")) {   // test hook: shows that an index was turned down
-				dwtx_set_error("the sidecar index does not fit the stream (DWTX_NO_INDEX_FALLBACK forbids the serial walk)");
+			if (ctx->opt[DWTX_OPT_NO_INDEX_FALLBACK]) {   // test hook: shows that an index was turned down
+				dwtx_set_error("the sidecar index does not fit the stream (DWTX_OPT_NO_INDEX_FALLBACK forbids the serial walk)");
 				return DWTX_ERR_DEVICE;
 			}
 			if ((rc2 = reset_part()) || (rc2 = walk(st, i0, cnt, fam0, false)))
@@ -2353,8 +2365,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 			DWTX_HIP(hipStreamSynchronize(st));
 		}
 		if (gave_up()) {
-			if (getenv("DWTX_NO_SECOND_WALK")) {   // test hook: shows that a stream takes this path
-				dwtx_set_error("the one-family token walk gave up (DWTX_NO_SECOND_WALK forbids the second)");
+			if (ctx->opt[DWTX_OPT_NO_SECOND_WALK]) {   // test hook: shows that a stream takes this path
+				dwtx_set_error("the one-family token walk gave up (DWTX_OPT_NO_SECOND_WALK forbids the second)");
 				return DWTX_ERR_DEVICE;
 			}
 			if ((rc2 = reset_part()) || (rc2 = pre(st, i0, cnt, FAM)) || (rc2 = walk(st, i0, cnt, FAM, false)))
@@ -2399,7 +2411,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		return DWTX_OK;
 	};
 	int rc;
-	if (n < 4 || getenv("DWTX_ONE_STREAM")) {
+	if (n < 4 || ctx->opt[DWTX_OPT_ONE_STREAM]) {
 		if ((rc = pre(s, 0, n, fam0)) || (rc = walk(s, 0, n, fam0, indexed(0, n))) || (rc = post(s, 0, n)))
 			return rc;
 		return done ? done(user, 0, n, part_mask[0]) : DWTX_OK;
@@ -2409,8 +2421,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	// of the parts after it and the scatter of the parts before it.  Four parts from 24 images on (measured on 64
 	// frames: 4096x4096 gray 10.6 -> 10.3 ms, 16 x 4096x4096 RGB 11.0 -> 10.8, 1080p RGB the same 6.7: there the
 	// walk itself, 2.5 ms whatever the part, and the last part's scatter are the critical path), else two.
-	const int K = getenv("DWTX_DECODE_PARTS") ? (atoi(getenv("DWTX_DECODE_PARTS")) < 2 ? 2 : atoi(getenv("DWTX_DECODE_PARTS")) > MAX_PARTS ? MAX_PARTS : atoi(getenv("DWTX_DECODE_PARTS")))
-		: (n >= 24 ? 4 : 2);
+	const long want_parts = ctx->opt[DWTX_OPT_DECODE_PARTS];
+	const int K = want_parts ? (want_parts < 2 ? 2 : want_parts > MAX_PARTS ? MAX_PARTS : (int)want_parts) : (n >= 24 ? 4 : 2);
 	for (int k = 0; k <= K; ++k)
 		part_first[k] = (int)((long)n * k / K);
 	for (int k = K + 1; k <= MAX_PARTS; ++k)
@@ -2423,33 +2435,40 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		ctx->have_more = true;
 	}
 	auto stream_of = [&](int k) { return k == 0 ? s : k == 1 ? ctx->aux : ctx->more[k - 2]; };
-	for (int k = 0; k < K; ++k) {
-		const int i0 = part_first[k], cnt = part_first[k + 1] - part_first[k];
-		hipStream_t st = stream_of(k);
-		if (k == 1)
-			DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[0], 0));
-		else if (k > 1)
-			DWTX_HIP(hipStreamWaitEvent(st, ctx->pev[k - 1], 0));   // after the tables of the part before (and, through them, after everything earlier on the main stream)
-		if ((rc = pre(st, i0, cnt, fam0)))
-			return rc;
-		if (k + 1 < K)
-			DWTX_HIP(hipEventRecord(k == 0 ? ctx->ev[0] : ctx->pev[k], st));
-		if ((rc = walk(st, i0, cnt, fam0, indexed(i0, cnt))))
-			return rc;
-	}
-	for (int k = 0; k < K; ++k) {   // each part's scatter as soon as its walk is over, then the caller's follow-up on the main stream
-		const int i0 = part_first[k], cnt = part_first[k + 1] - part_first[k];
-		if ((rc = post(stream_of(k), i0, cnt)))
-			return rc;
-		if (k > 0) {
-			hipEvent_t ev = k == 1 ? ctx->ev[1] : ctx->pev[4 + k];
-			DWTX_HIP(hipEventRecord(ev, stream_of(k)));
-			DWTX_HIP(hipStreamWaitEvent(s, ev, 0));
+	auto run_parts = [&]() -> int {
+		for (int k = 0; k < K; ++k) {
+			const int i0 = part_first[k], cnt = part_first[k + 1] - part_first[k];
+			hipStream_t st = stream_of(k);
+			if (k == 1)
+				DWTX_HIP(hipStreamWaitEvent(st, ctx->ev[0], 0));
+			else if (k > 1)
+				DWTX_HIP(hipStreamWaitEvent(st, ctx->pev[k - 1], 0));   // after the tables of the part before (and, through them, after everything earlier on the main stream)
+			if ((rc = pre(st, i0, cnt, fam0)))
+				return rc;
+			if (k + 1 < K)
+				DWTX_HIP(hipEventRecord(k == 0 ? ctx->ev[0] : ctx->pev[k], st));
+			if ((rc = walk(st, i0, cnt, fam0, indexed(i0, cnt))))
+				return rc;
 		}
-		if (done && (rc = done(user, i0, cnt, part_mask[k])))
-			return rc;
-	}
-	return DWTX_OK;
+		for (int k = 0; k < K; ++k) {   // each part's scatter as soon as its walk is over, then the caller's follow-up on the main stream
+			const int i0 = part_first[k], cnt = part_first[k + 1] - part_first[k];
+			if ((rc = post(stream_of(k), i0, cnt)))
+				return rc;
+			if (k > 0) {
+				hipEvent_t ev = k == 1 ? ctx->ev[1] : ctx->pev[4 + k];
+				DWTX_HIP(hipEventRecord(ev, stream_of(k)));
+				DWTX_HIP(hipStreamWaitEvent(s, ev, 0));
+			}
+			if (done && (rc = done(user, i0, cnt, part_mask[k])))
+				return rc;
+		}
+		return DWTX_OK;
+	};
+	rc = run_parts();
+	if (rc)   // a part failed: what the other parts still have queued on their streams uses the shared tables — it
+		for (int k = 1; k < K; ++k)   // must be over before the caller (or the next call's clears) touches them
+			(void)hipStreamSynchronize(stream_of(k));
+	return rc;
 }
 
 extern "C" int dwtx_decode_planes(dwtx_ctx *ctx, int32_t *lin, const uint8_t *streams, size_t stream_stride,

@@ -82,7 +82,9 @@ typedef struct dwtx_stream_info {
 
 /* Per-image result record of the decoder's entropy stage (host memory). */
 typedef struct dwtx_decode_info {
-	int status;                    /* 0 ok; 1 = header, root image or plane counts unreadable (decode.c exits 1) */
+	int status;                    /* 0 ok; 1 = header, root image or plane counts unreadable (decode.c exits 1);
+	                                * 2 = the stream claims more than 16 bit planes: refused (decode.c:183-186 would go on;
+	                                * only damage produces such a count — the one documented difference) */
 	int W, H, C;
 	int levels;
 	int planes[3];                 /* decode.c:183-186 */
@@ -141,6 +143,25 @@ int dwtx_sync(dwtx_ctx *ctx);
  * dwtx_ctx_set_index(ctx, NULL, NULL) ends it. */
 int dwtx_ctx_set_index(dwtx_ctx *ctx, const dwtx_index *in, dwtx_index *out);
 void *dwtx_stream(dwtx_ctx *ctx);
+
+/* Diagnostic switches of a context, all off (0) by default.  They exist for the tests, the profiling tools and
+ * the CLIs' debugging aids: none of them changes a result, they choose between code paths that must agree
+ * (DESIGN.md section 8).  The library itself reads no environment variables. */
+enum dwtx_option {
+	DWTX_OPT_EXACT_ORDERS = 0,     /* encoder: every image takes the exact 32-state VLI-order pass */
+	DWTX_OPT_NO_SQUARE_TILES,      /* no tiles straight from / to the pyramid: everything through the linearised copy */
+	DWTX_OPT_PART_IMAGES,          /* host-buffer pipelines: images per part (0 = automatic) */
+	DWTX_OPT_ONE_STREAM,           /* decoder: the whole batch on one HIP stream (clean per-kernel profiles) */
+	DWTX_OPT_DECODE_PARTS,         /* decoder: parts a batch is cut into, 2..4 (0 = automatic) */
+	DWTX_OPT_TWO_FAMILIES,         /* decoder: both speculative path families from the start */
+	DWTX_OPT_NO_SECOND_WALK,       /* decoder: a token walk that gives up is an error instead of being repeated */
+	DWTX_OPT_NO_INDEX,             /* decoder: offered sidecar indices are ignored */
+	DWTX_OPT_NO_INDEX_FALLBACK,    /* decoder: an index that is turned down is an error instead of the serial walk */
+	DWTX_OPT_NO_CAPACITY_CUT,      /* encoder: CAPACITY only clips the finished stream (all segments are coded) */
+	DWTX_OPT_COUNT
+};
+int dwtx_ctx_set_option(dwtx_ctx *ctx, int option, long value);
+long dwtx_ctx_get_option(dwtx_ctx *ctx, int option);
 
 void *dwtx_malloc(dwtx_ctx *ctx, size_t bytes);
 void dwtx_free(dwtx_ctx *ctx, void *dev);
@@ -230,7 +251,8 @@ int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, size_t stream_
 /* Host-buffer wrappers: what encode.c:133-232 / decode.c:136-268 do between
  * read_pnm/write_pnm and the byte sink.  pixels_max < 0 = no PIXELS argument.
  * dwtx_decode_images returns DWTX_ERR_ARG for a bad header and DWTX_ERR_IO when
- * the root image or plane counts cannot be read (both exit code 1 in decode.c). */
+ * the root image or plane counts cannot be read (both exit code 1 in decode.c); a
+ * single stream that claims more than 16 bit planes is DWTX_ERR_ARG too (status 2). */
 int dwtx_encode_images(dwtx_ctx *ctx, const uint8_t *host_pix, int W, int H, int C, int n, long capacity,
 	uint8_t *host_out, size_t out_stride, size_t *out_lens, dwtx_stats *stats);
 int dwtx_decode_images(dwtx_ctx *ctx, const uint8_t *host_streams, size_t stream_stride, const size_t *lens, int n,

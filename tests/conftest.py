@@ -30,3 +30,18 @@ def ctx():
     c = dwt_amd.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def opts(ctx):
+    """Diagnostic switches of the shared context (enum dwtx_option, include/dwtx.h), back to 0 after the test."""
+    used = []
+
+    class Opts:
+        def set(self, name, value=1):
+            used.append(name)
+            ctx.set_option(name, value)
+
+    yield Opts()
+    for name in used:
+        ctx.set_option(name, 0)

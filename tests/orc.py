@@ -197,3 +197,36 @@ def write_pnm(path, pix):
 
 def have_ref():
     return os.path.exists(os.path.join(REF_DIR, "encode")) and os.path.exists(os.path.join(REF_DIR, "decode"))
+
+
+def many_plane_stream(W, H, Cn, planes, payload_seed=1, payload_len=600):
+    """A .dwt whose preamble is well-formed — header, all-zero root images, plane counts `planes` (one per channel) —
+    followed by seeded random bytes: plane counts above 16 are what only damage can produce (8-bit sources stay
+    below 12).  decode.c:183-186 accepts any get_vli() value."""
+    bits = []
+    order = 0
+
+    def vli(v):   # vli.h:67-84 in closed form (SURVEY 5.7)
+        nonlocal order
+        top = (v + (1 << order)).bit_length() - 1
+        bits.extend([0] * (top - order) + [1])
+        rem = v + (1 << order) - (1 << top)
+        bits.extend((rem >> i) & 1 for i in range(top))
+        order = max(top - 2, 0)
+
+    for _ in range(Cn):
+        vli(0)            # encode.c:97-110: cnt = 0, no root values follow
+    for p in planes[:Cn]:
+        vli(p)
+    body = bytearray(b"W" + (b"6" if Cn == 3 else b"5") + bytes([(W - 1) & 255, (W - 1) >> 8, (H - 1) & 255, (H - 1) >> 8]))
+    acc = 0
+    for i, b in enumerate(bits):
+        acc |= b << (i & 7)
+        if (i & 7) == 7:
+            body.append(acc)
+            acc = 0
+    rng = np.random.default_rng(payload_seed)
+    tail = rng.integers(0, 256, payload_len, dtype=np.uint8)
+    if len(bits) & 7:   # the payload starts inside the last preamble byte
+        body.append(acc | (int(tail[0]) << (len(bits) & 7)) & 255)
+    return bytes(body) + tail.tobytes()

@@ -314,3 +314,15 @@ def test_damaged_streams_decode_like_the_reference_binary(tmp_path, name, said):
     r = run(DEC, src, pnm)
     assert r.returncode == 0 and r.stderr == said   # what oracle/_ref/decode says (tests/test_oracle.py pins it)
     assert (orc.read_pnm(pnm) == orc.decode(open(src, "rb").read())).all()
+
+
+def test_a_stream_that_claims_more_than_16_bit_planes_is_refused_with_a_message(tmp_path):
+    """The one documented difference from the reference: decode.c:183-186 accepts any plane
+    count and decodes such a — necessarily damaged — stream to garbage with exit code 0; this decoder handles
+    at most 16 planes, says so on stderr and exits 1 without writing a picture."""
+    dwt, pnm, ref_pnm = str(tmp_path / "m.dwt"), str(tmp_path / "m.pnm"), str(tmp_path / "r.pnm")
+    open(dwt, "wb").write(orc.many_plane_stream(40, 24, 1, [20], 1))
+    r = run(DEC, dwt, pnm)
+    assert r.returncode == 1 and b"more than 16 bit planes" in r.stderr and not os.path.exists(pnm)
+    if orc.have_ref():
+        assert run(os.path.join(orc.REF_DIR, "decode"), dwt, ref_pnm).returncode == 0 and os.path.exists(ref_pnm)

@@ -244,11 +244,11 @@ def test_random_shapes_capacities_and_cuts(ctx):
             assert (want is None and got is None) or (got.shape == want.shape and (got == want).all()), (W, H, Cn, cap, px)
 
 
-def test_host_batches_pipeline_in_parts(ctx, monkeypatch):
+def test_host_batches_pipeline_in_parts(ctx, opts):
     """The host-buffer entry points cut a batch into parts whose transfers overlap the neighbouring
     parts' kernels; with parts of 3 images an 11-image batch takes four of them (both staging slots
     get reused), one stream cut short."""
-    monkeypatch.setenv("DWTX_PART_IMAGES", "3")
+    opts.set("part_images", 3)
     n, H, W, Cn = 11, 72, 100, 3
     pix = np.stack([orc.synth(W, H, Cn, 500 + i, i & 1) for i in range(n)])
     streams, stats = ctx.encode(pix)
@@ -378,7 +378,7 @@ def test_config_c_1024_frames_of_1080p_rgb_in_one_call(ctx):
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 1), (128, 128, 3), (256, 256, 1), (512, 512, 3)])
-def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, monkeypatch):
+def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, opts):
     """Full power-of-two square levels skip the linearised copy: the coder reads their tiles from the pyramid's
     32x32 Hilbert squares and the decoder writes them there (bias of never-decoded planes included,
     decode.c:51-58).  Same bytes and pictures as the oracle, whole and cut at many lengths (cuts inside the
@@ -407,7 +407,7 @@ def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, mo
     for i in range(n):
         want = orc.decode(streams[i])
         assert outs[i].shape == want.shape and (outs[i] == want).all(), i
-    monkeypatch.setenv("DWTX_NO_SQUARE_TILES", "1")
+    opts.set("no_square_tiles", 1)
     plain, _ = ctx.encode(pixs)
     assert plain == [orc.encode(pixs[i])[0] for i in range(n)]
     outs2 = ctx.decode(streams)
@@ -416,7 +416,7 @@ def test_power_of_two_squares_read_and_write_the_pyramid_directly(ctx, shape, mo
 
 
 @pytest.mark.parametrize("parts", ["2", "3", "4"])
-def test_decode_batches_in_two_three_or_four_parts(ctx, parts, monkeypatch):
+def test_decode_batches_in_two_three_or_four_parts(ctx, parts, opts):
     """A decode batch runs as parts on streams of their own (unpack.hip dwtx_decode_planes_ex; four from 24 images on):
     whole, cut and damaged streams of one geometry, 29 of them, come out the same however the batch is cut."""
     from test_oracle import corrupted_blobs
@@ -425,7 +425,7 @@ def test_decode_batches_in_two_three_or_four_parts(ctx, parts, monkeypatch):
     good = [orc.encode(orc.synth(W, H, Cn, 70 + i, i & 1))[0] for i in range(17)]
     blobs = good + [g[: len(g) * (i + 2) // 9] for i, g in enumerate(good[:6])] + corrupted_blobs(good[0], 6, 3)
     want = [orc.decode(b) for b in blobs]
-    monkeypatch.setenv("DWTX_DECODE_PARTS", parts)
+    opts.set("decode_parts", int(parts))
     got = ctx.decode(blobs)
     for w, g in zip(want, got):
         assert (w is None and g is None) or (g is not None and g.shape == w.shape and (g == w).all())

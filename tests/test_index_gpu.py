@@ -26,7 +26,7 @@ def _same_info(a, b):
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 1), (53, 37, 3), (255, 257, 1), (360, 640, 3), (512, 512, 1)])
-def test_a_decode_writes_an_index_and_a_decode_with_it_gives_the_same(ctx, shape, monkeypatch):
+def test_a_decode_writes_an_index_and_a_decode_with_it_gives_the_same(ctx, shape, opts):
     import dwt_amd
 
     H, W, Cn = shape
@@ -39,7 +39,7 @@ def test_a_decode_writes_an_index_and_a_decode_with_it_gives_the_same(ctx, shape
         assert made[i].magic == dwt_amd.INDEX_MAGIC and made[i].nsegs == winfos[i].nsegs > 0
         assert made[i].seg[0].bit > 48 and made[i].stream_bits == winfos[i].bits_used
     # with the index; DWTX_NO_INDEX_FALLBACK turns a rejected index into an error: these must all be accepted
-    monkeypatch.setenv("DWTX_NO_INDEX_FALLBACK", "1")
+    opts.set("no_index_fallback", 1)
     again = ctx.set_index(made, len(streams))
     got, ginfos = _decode(ctx, streams, W, H, Cn)
     assert (got == want).all()
@@ -57,7 +57,7 @@ def test_a_decode_writes_an_index_and_a_decode_with_it_gives_the_same(ctx, shape
     ctx.set_index()
 
 
-def test_a_wrong_index_changes_nothing(ctx, monkeypatch):
+def test_a_wrong_index_changes_nothing(ctx, opts):
     """Stale, foreign and damaged indices: the decoder notices (the segments do not fit together) and walks the
     stream the plain way; with DWTX_NO_INDEX_FALLBACK the rejection shows as an error."""
     import dwt_amd
@@ -98,10 +98,10 @@ def test_a_wrong_index_changes_nothing(ctx, monkeypatch):
         assert (got == want).all(), kind
         for a, b in zip(ginfos, winfos):
             _same_info(a, b)
-        monkeypatch.setenv("DWTX_NO_INDEX_FALLBACK", "1")
+        opts.set("no_index_fallback", 1)
         with pytest.raises(dwt_amd.DwtxError):
             _decode(ctx, streams, W, H, Cn)
-        monkeypatch.delenv("DWTX_NO_INDEX_FALLBACK")
+        opts.set("no_index_fallback", 0)
     ctx.set_index()
 
 
@@ -123,7 +123,7 @@ def test_cut_streams_have_no_index_and_take_none(ctx):
     ctx.set_index()
 
 
-def test_whole_images_through_the_host_pipeline_with_an_index(ctx, monkeypatch):
+def test_whole_images_through_the_host_pipeline_with_an_index(ctx, opts):
     """dwtx_decode_images decodes a batch in parts: index entries follow their images."""
     import dwt_amd
 
@@ -134,8 +134,8 @@ def test_whole_images_through_the_host_pipeline_with_an_index(ctx, monkeypatch):
     outs = ctx.decode(streams)
     assert all((o == p).all() for o, p in zip(outs, pix))
     assert all(m.nsegs > 0 for m in made)
-    monkeypatch.setenv("DWTX_PART_IMAGES", "3")
-    monkeypatch.setenv("DWTX_NO_INDEX_FALLBACK", "1")
+    opts.set("part_images", 3)
+    opts.set("no_index_fallback", 1)
     ctx.set_index(made, 0)
     outs = ctx.decode(streams)
     assert all((o == p).all() for o, p in zip(outs, pix))

@@ -185,6 +185,29 @@ def test_corrupted_streams_against_reference_binary(tmp_path):
             assert back is not None and ref.shape == back.shape and (ref == back).all()
 
 
+MANY_PLANES = [(40, 24, 1, [17]), (40, 24, 1, [20]), (24, 40, 3, [9, 29, 3]), (64, 64, 1, [24]), (37, 53, 3, [18, 18, 18])]
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("case", MANY_PLANES)
+def test_streams_that_claim_more_than_16_bit_planes_against_reference_binary(tmp_path, case):
+    """decode.c:183-186 takes whatever plane count get_vli() returns; only a damaged stream can claim more than 16
+    (8-bit sources stay below 12).  The reference decodes such a stream (to garbage) and so does the restatement,
+    bit for bit; the GPU decoder refuses it — status 2, tests/test_unpack_gpu.py — which is the one documented
+    difference."""
+    W, H, Cn, planes = case
+    for seed in (1, 2, 3):
+        blob = orc.many_plane_stream(W, H, Cn, planes, seed)
+        dwt, dec = str(tmp_path / "m.dwt"), str(tmp_path / "m.pnm")
+        open(dwt, "wb").write(blob)
+        r = subprocess.run([os.path.join(orc.REF_DIR, "decode"), dwt, dec], capture_output=True, timeout=120)
+        assert r.returncode == 0
+        st = orc.decode_stage(blob, W, H, Cn, -1)
+        assert st is not None and st[3] == planes[:Cn]
+        back, ref = orc.decode(blob), orc.read_pnm(dec)
+        assert back is not None and ref.shape == back.shape and (ref == back).all()
+
+
 DAMAGED = [("damaged_order_beyond_31_47x650x1.dwt", 47, 650, 1, b""), ("damaged_wide_root_213x18x3.dwt", 213, 18, 3, b"509 zeros not read.\n")]
 
 

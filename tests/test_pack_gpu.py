@@ -138,7 +138,7 @@ def _parity_locked_planes(W, H, sign, extra):
 
 
 @pytest.mark.parametrize("sign", [1, -1])
-def test_streams_the_single_path_family_cannot_follow(ctx, sign, monkeypatch):
+def test_streams_the_single_path_family_cannot_follow(ctx, sign, opts):
     """The decoder records ONE family of speculative paths per chunk and falls back to two (even and odd start) when
     its token walk gives up; a ring of equal +-1 coefficients locks the parity for ~100 000 tokens.  Either way the
     planes must come back exactly, and at least one of the variants must really have taken the second walk."""
@@ -159,7 +159,7 @@ def test_streams_the_single_path_family_cannot_follow(ctx, sign, monkeypatch):
         assert (back.cpu().numpy() == lin).all()
     back, infos = ctx.decode_planes(streams, W, H, 1)   # as one batch (parts of it walk again, others do not)
     assert (back.cpu().numpy() == np.concatenate(variants)).all()
-    monkeypatch.setenv("DWTX_NO_SECOND_WALK", "1")
+    opts.set("no_second_walk", 1)
     gave_up = 0
     for s in streams:
         try:
@@ -167,7 +167,7 @@ def test_streams_the_single_path_family_cannot_follow(ctx, sign, monkeypatch):
         except dwt_amd.DwtxError:
             gave_up += 1
     assert 0 < gave_up
-    monkeypatch.delenv("DWTX_NO_SECOND_WALK")
-    monkeypatch.setenv("DWTX_TWO_FAMILIES", "1")   # both families from the start: the path the fallback takes
+    opts.set("no_second_walk", 0)
+    opts.set("two_families", 1)   # both families from the start: the path the fallback takes
     back, infos = ctx.decode_planes(streams, W, H, 1)
     assert (back.cpu().numpy() == np.concatenate(variants)).all()

@@ -19,6 +19,9 @@ def check(ctx, data_list, W, H, Cn, levels_max=-1, pixels_max=-1):
             assert infos[i].status == 1
             continue
         rlin, level, missing, planes = ref
+        if max(planes) > 16:   # the documented difference: the reference decodes on, this decoder refuses
+            assert infos[i].status == 2
+            continue
         assert infos[i].status == 0
         assert list(infos[i].planes)[:Cn] == planes
         assert infos[i].level == level
@@ -79,23 +82,34 @@ def test_bad_headers(ctx):
 
 
 @pytest.mark.parametrize("shape", [(53, 37, 3), (255, 257, 1), (360, 640, 3)])
-def test_both_path_families_from_the_start(ctx, shape, monkeypatch):
+def test_both_path_families_from_the_start(ctx, shape, opts):
     """The decoder normally records one family of speculative paths and only falls back to two (even / odd start,
     unpack.hip k_spec) when its token walk gives up.  DWTX_TWO_FAMILIES starts with both: whole streams, prefixes
     and damaged streams must decode exactly as with one."""
     from test_oracle import corrupted_blobs
 
-    monkeypatch.setenv("DWTX_TWO_FAMILIES", "1")
+    opts.set("two_families", 1)
     H, W, Cn = shape
     data, _ = orc.encode(orc.synth(W, H, Cn, 31, 0))
     step = max(1, len(data) // 150)
     check(ctx, [data] + [data[:k] for k in range(1, len(data), step)], W, H, Cn)
-    blobs = []
-    for blob in corrupted_blobs(data, 24, 11):   # plane counts above 16 only damage can produce: refused by design (DESIGN.md section 7)
-        ref = orc.decode_stage(blob, W, H, Cn, -1)
-        if ref is None or max(ref[3]) <= 16:
-            blobs.append(blob)
-    check(ctx, blobs, W, H, Cn)
+    check(ctx, corrupted_blobs(data, 24, 11), W, H, Cn)   # (a blob that claims more than 16 planes must come back with status 2)
+
+
+@pytest.mark.parametrize("case", [(40, 24, 1, [17]), (40, 24, 1, [20]), (24, 40, 3, [9, 29, 3]), (64, 64, 1, [24]), (37, 53, 3, [18, 18, 18])])
+def test_streams_that_claim_more_than_16_bit_planes_are_refused(ctx, case):
+    """decode.c:183-186 accepts any plane count; the reference (and the oracle, pinned on it by tests/test_oracle.py
+    on these very streams) decodes such a stream to garbage.  This decoder handles at most 16 planes and says so:
+    status 2 for that stream, alone and inside a batch whose other streams decode as always."""
+    W, H, Cn, planes = case
+    good, _ = orc.encode(orc.synth(W, H, Cn, 3, 0))
+    bad = [orc.many_plane_stream(W, H, Cn, planes, seed) for seed in (1, 2, 3)]
+    for b in bad:
+        assert orc.decode_stage(b, W, H, Cn, -1)[3] == planes[:Cn]   # the oracle reads the claim and decodes on
+    check(ctx, [bad[0]], W, H, Cn)
+    check(ctx, [good, bad[0], good[:len(good) // 2], bad[1], bad[2], good], W, H, Cn)
+    _, infos = ctx.decode_planes([bad[0], good], W, H, Cn)
+    assert [i.status for i in infos] == [2, 0]
 
 
 @pytest.mark.parametrize("case", [("damaged_order_beyond_31_47x650x1.dwt", 47, 650, 1), ("damaged_wide_root_213x18x3.dwt", 213, 18, 3)])

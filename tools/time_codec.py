@@ -7,6 +7,9 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else W
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 ctx = dwt_amd.Context(0)
+for name in dwt_amd._lib.OPTIONS:   # the library reads no environment: DWTX_ONE_STREAM=1 etc. are this tool's switches
+    if os.environ.get("DWTX_" + name.upper()):
+        ctx.set_option(name, int(os.environ["DWTX_" + name.upper()]))
 pix = ctx.synth_pixels(n, H, W, C, 0, 0)
 streams, info = ctx.encode_device(pix)
 lens = ctx.stream_lengths(info)
