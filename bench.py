@@ -148,7 +148,11 @@ class Runner:
         t0 = time.perf_counter()
         for _ in range(steps):
             last = self.step()
+        t1 = time.perf_counter()
         self.drain()
+        self.torch.cuda.synchronize()
+        self.own_s = time.perf_counter() - t0     # this rank's own steps and its part of the last gather, before the barrier
+        self.drain_s = time.perf_counter() - t1   # of which: finishing the device work in flight and the last step's gather
         fence()
         return time.perf_counter() - t0, last, k0
 
@@ -261,10 +265,16 @@ def main():
     run = Runner(ctx, torch, dwt_amd, args.workload, args.frames, rank, world, dev)
     W, H, C, B = run.W, run.H, run.C, run.B
     elapsed, (streams, lens, d, dinfos), k0 = run.timed(args.steps, args.warmup, fence)
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what each rank spent on its own (so that a scaling run explains itself: a slow rank, or rank 0 paying for the gather)
+        mine = torch.tensor([run.own_s, run.drain_s], dtype=torch.float64, device=dev)
+        every = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every.view(-1), mine)
+        per_rank = every.cpu().tolist()
 
     # ---- verification (outside the timed region) ---------------------------------
     pix = run.pix
@@ -283,6 +293,11 @@ def main():
             # rank 0's own rows of the gathered set must be the streams it encoded
             mine_ok = all(bool(torch.equal(bufs[0][i, : lens_host[i]].to(dev), streams[i, : lens_host[i]])) for i in range(B))
             gathered = {"world": world, "backend": args.backend, "frames": world * B, "own_rows_match": mine_ok,
+                        "per_rank_ms_per_step": [round(o / args.steps * 1e3, 3) for o, _ in per_rank],
+                        "per_rank_drain_ms": [round(dr * 1e3, 3) for _, dr in per_rank],
+                        "note": "per_rank_ms_per_step = a rank's own wall time for its steps incl. its share of the gather, before the "
+                                "closing barrier; per_rank_drain_ms = after the last step was queued: device work still in flight "
+                                "plus the last step's gather (the only one that cannot hide behind a following step)",
                         "bytes_last_step": int(all_lens.sum()),
                         "bytes_all_steps_incl_warmup": run.gather.bytes_gathered, "bytes_per_rank_last_step": [int(all_lens[r * B:(r + 1) * B].sum()) for r in range(world)]}
             if args.dump_gathered:

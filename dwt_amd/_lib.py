@@ -26,7 +26,7 @@ class Geom(C.Structure):
 class StreamInfo(C.Structure):
     _fields_ = [
         ("planes", C.c_int * 3), ("pmax", C.c_int), ("segments", C.c_int), ("entries", C.c_int),
-        ("tokens", C.c_uint), ("order0", C.c_int), ("hdr_bits", C.c_uint), ("root_bits", C.c_uint), ("meta_bits", C.c_uint), ("reserved0", C.c_uint),
+        ("tokens", C.c_uint), ("order0", C.c_int), ("hdr_bits", C.c_uint), ("root_bits", C.c_uint), ("meta_bits", C.c_uint), ("segments_cut", C.c_uint),
         ("total_bits", C.c_ulonglong), ("nbytes", C.c_ulonglong), ("error", C.c_int), ("exact_orders", C.c_int),
     ]
 

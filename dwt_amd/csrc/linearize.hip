@@ -353,6 +353,16 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 	ctx->plans = nullptr;
 }
 
+// curve blocks up to the last level (below `levels`) that is copied at all: the blocks are numbered level by level
+static int blocks_needed(const LinGeom &g, int levels, unsigned skip_levels)
+{
+	int nb = 0;
+	for (int l = 0; l < levels && l < g.levels; ++l)
+		if (!((skip_levels >> l) & 1u))
+			nb = g.blk_first[l + 1];
+	return nb;
+}
+
 unsigned dwtx_square_levels(int W, int H)
 {
 	dwtx_geom g;
@@ -388,8 +398,10 @@ int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W
 	const long ps = (long)W * H;
 	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
 		g.widths[0], g.heights[0], lin, ps, const_cast<int *>(pyr), ps, W);
-	hipLaunchKernelGGL(k_ring_copy<false>, dim3(p->nblocks, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
-		g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels);
+	const int nb = blocks_needed(g, g.levels, skip_levels);   // (a grid over the skipped levels' blocks would only start and end)
+	if (nb)
+		hipLaunchKernelGGL(k_ring_copy<false>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
+			g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
@@ -425,8 +437,10 @@ int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, cons
 		g.widths[0], g.heights[0], const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow);
 	if (levels_out > 0) {
 		g.levels = levels_out;   // only rings 0..levels_out-1 are rebuilt
-		hipLaunchKernelGGL(k_ring_copy<true>, dim3(g.blk_first[levels_out], dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
-			ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels);
+		const int nb = blocks_needed(g, levels_out, skip_levels);
+		if (nb)
+			hipLaunchKernelGGL(k_ring_copy<true>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
+				ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels);
 	}
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;

@@ -83,7 +83,7 @@ struct ImgInfo {
 	unsigned hdr_bits;
 	unsigned root_bits;
 	unsigned meta_bits;
-	unsigned pad0;
+	unsigned cut;          // segments of the schedule that are not coded: they start beyond CAPACITY (k_cut)
 	unsigned long long total_bits;
 	unsigned long long nbytes;
 	int error;
@@ -98,6 +98,7 @@ struct RunMap {
 struct Work {
 	// per plane
 	unsigned short *cum;        // [nplanes][NT][32]
+	unsigned char *tile_top;    // [nplanes][NTP] every tile's own bit-plane count, 1 + ilog2(max |v|) (k_hist -> k_plan, k_code); NTP = NT rounded up to 16
 	// per image
 	ImgInfo *info;              // [n]
 	int *seg_desc;              // [n][MAX_SEGS]   c | l<<4 | (p+1)<<8
@@ -107,6 +108,7 @@ struct Work {
 	unsigned long long *seg_stage;  // [n][MAX_SEGS+1] word offset of the segment's refinement block in the staging buffer
 	unsigned *brk_tok;          // [n][MAX_SEGS] token index of the segment's break slot
 	int *segidx;                // [n][3][16][MAX_PLANES] -> k+1 of the segment coding (channel, level, plane)
+	unsigned *live;             // [n][3][16] bit p: plane p of (channel, level) is coded (its segment starts inside CAPACITY; k_cut)
 	// per entry
 	unsigned short *ent_ones, *ent_zeros, *ent_refs, *ent_tz;   // [n][ES]
 	unsigned short *ent_seg;    // [n][ES] the entry's segment (k_entries_count looks it up once)
@@ -133,7 +135,7 @@ struct Work {
 	unsigned long long *stream_bits;   // [n] bits of the whole stream before any capacity clip (k_bitscan -> k_clear_stream)
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
 	long ES, TS, NCS, NGS, NCB, SW;
-	int NT;
+	int NT, NTP;
 };
 
 __device__ __forceinline__ int lane_id()
@@ -359,6 +361,8 @@ __device__ __forceinline__ void hist_finish(const Work &w, int plane, int tile, 
 		// cannot hold a device-coherent word, and that cost 0.7 ms per 400 000 tiles.)
 		cum[lane] = (unsigned short)(lane == NCUM - 1 ? (mx ? ilog2u(mx) + 1 : 0) : nvalid);
 	}
+	if (lane == 0)   // the same count once more in a dense array: k_plan reduces it, k_code asks it before loading the tile
+		w.tile_top[(long)plane * w.NTP + tile] = (unsigned char)(mx ? (ilog2u(mx) + 1 < 255 ? ilog2u(mx) + 1 : 255) : 0);
 }
 
 // Two tiles per wave: both tiles' loads are in flight before the first is counted (the kernel only waits for memory).
@@ -461,20 +465,21 @@ __global__ __launch_bounds__(1024) void k_plan(PackGeom g, const int *__restrict
 	if (threadIdx.x < 3)
 		top_of[threadIdx.x] = 0;
 	__syncthreads();
-	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count: maximum over its tiles (k_hist left one value per tile)
-		const unsigned short *cum = w.cum + (long)(img * g.C + c) * w.NT * NCUM + (NCUM - 1);
-		int top = 0;
-		for (int t0 = threadIdx.x; t0 < w.NT; t0 += 8 * blockDim.x) {   // eight loads in flight, not one after the other
-			unsigned short v[8];
+	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count: maximum over its tiles (k_hist left one byte per tile, rows padded to 16)
+		const uint4 *tt = reinterpret_cast<const uint4 *>(w.tile_top + (long)(img * g.C + c) * w.NTP);
+		unsigned m = 0;   // byte-wise maximum of 16 tiles at a time
+		for (int q = threadIdx.x; q * 16 < w.NT; q += blockDim.x) {
+			const uint4 v = tt[q];
+			const unsigned x[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				const int t = t0 + u * (int)blockDim.x;
-				v[u] = t < w.NT ? cum[(long)t * NCUM] : (unsigned short)0;
-			}
+			for (int u = 0; u < 4; ++u)
 #pragma unroll
-			for (int u = 0; u < 8; ++u)
-				top = max(top, (int)v[u]);
+				for (int bb = 0; bb < 4; ++bb) {
+					const unsigned e = (x[u] >> (8 * bb)) & 0xffu;
+					m = q * 16 + u * 4 + bb < w.NT ? max(m, e) : m;
+				}
 		}
+		int top = (int)m;
 		for (int o = 32; o; o >>= 1)
 			top = max(top, __shfl_xor(top, o));
 		if ((threadIdx.x & 63) == 0)
@@ -766,6 +771,60 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_stage_zero(Work w)
 	st[(bit0 + refs - 1) >> 5] = 0u;
 }
 
+// ------------------------------------------------------------------- k_cut ---
+// encode.c:192,204,216: the reference leaves its plane loop at the first byte the sink refuses (bytes.h:75-78), so
+// what follows that point in the schedule is never coded.  Here the stream's bits are only known at the end
+// (k_bitscan), but a lower bound is known now: a one costs at least two bits (the bit that ends its VLI,
+// vli.h:67-84, and its sign), a refinement bit costs itself.  A segment whose first bit — by that bound — lies at or
+// beyond bit 8 * (CAPACITY + 1) cannot reach the output: it and everything after it is dropped from the work of
+// k_code, the carry scan, the order pass and the emitter (K, E, T shrink; `live` tells k_code which planes of a
+// (channel, level) are still coded: tiles with none are not even loaded).  The exact clip stays in k_bitscan; the
+// bytes are the same prefix of the unlimited stream.
+__global__ __launch_bounds__(ENT_BLOCK) void k_cut(Work w, long capacity, int cut_off)
+{
+	__shared__ unsigned long long need[MAX_SEGS];
+	__shared__ int kc_sh;
+	const int img = blockIdx.x;
+	ImgInfo &I = w.info[img];
+	const int K = I.K;
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1);
+	const int k = threadIdx.x;
+	if (k < K) {
+		const unsigned ones = tokbase[eb[k + 1]] - tokbase[eb[k]] - 1u;   // (the segment's break slot is not a one)
+		need[k] = 2ull * ones + w.seg_refs[(long)img * MAX_SEGS + k];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int kc = K;
+		if (capacity > 0 && !cut_off) {
+			const unsigned long long limit = 8ull * ((unsigned long long)capacity + 1ull);
+			unsigned long long at = I.hdr_bits;
+			for (int j = 0; j < K; ++j) {
+				if (at >= limit) {
+					kc = j;
+					break;
+				}
+				at += need[j];
+			}
+		}
+		kc_sh = kc;
+		I.cut = (unsigned)(K - kc);
+		I.K = kc;
+		I.E = eb[kc];
+		I.T = tokbase[eb[kc]] + 1u;   // + the final flush's slot (encode.c:221; beyond the clip whenever something was cut)
+	}
+	__syncthreads();
+	const int kc = kc_sh;
+	if (threadIdx.x < 48) {
+		const int *sx = w.segidx + ((long)img * 48 + threadIdx.x) * MAX_PLANES;
+		unsigned m = 0;
+		for (int p = 0; p < MAX_PLANES; ++p)
+			m |= (sx[p] && sx[p] <= kc ? 1u : 0u) << p;
+		w.live[(long)img * 48 + threadIdx.x] = m;
+	}
+}
+
 // ------------------------------------------------------------------ k_code ---
 // One wave per 1024-coefficient tile; lane L owns coefficients 16L .. 16L+15 of the tile, so everything
 // that is sequential in the reference's scan order (encode.c:60-95) is sequential inside a lane and a
@@ -1027,6 +1086,20 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	const long base = g.pixels[l] + (long)j * TILE;
 	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
 	const int P = I.planes[c] < MAX_PLANES ? I.planes[c] : MAX_PLANES;
+	const unsigned live = w.live[(long)img * 48 + c * 16 + l];   // planes of this ring that are coded (k_cut)
+	if (!live)
+		return;   // (uniform) everything this tile could add lies beyond CAPACITY
+	// Coded planes at or above the tile's own bit-plane count see nothing but zeros: no tokens, no refinement bits, the
+	// tile just hands its coefficients on to the run counter (k_carry_*).  When that is all there is — the finest
+	// rings' high planes under a CAPACITY that cut the low ones off — the coefficients are not even loaded.
+	const int tile_top = w.tile_top[(long)plane * w.NTP + tile];
+	if (!(live & ((1u << (tile_top < 31 ? tile_top : 31)) - 1u))) {   // uniform
+		if (lane < MAX_PLANES && ((live >> lane) & 1u)) {
+			const int k = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + lane] - 1;
+			w.ent_tz[img * w.ES + w.seg_ebase[(long)img * (MAX_SEGS + 1) + k] + j] = (unsigned short)nvalid;
+		}
+		return;
+	}
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;   // this lane's coefficients
 	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
@@ -1042,7 +1115,7 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	unsigned long long my_rb = 0;
 	if (lane < MAX_PLANES) {
 		const int p = lane;
-		const int k1 = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p];
+		const int k1 = (live >> p) & 1u ? w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + p] : 0;
 		if (k1) {
 			const int k = k1 - 1;
 			const int e0 = w.seg_ebase[(long)img * (MAX_SEGS + 1) + k];
@@ -2074,6 +2147,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	Work w;
 	memset(&w, 0, sizeof(w));
 	w.NT = NT;
+	w.NTP = (NT + 15) / 16 * 16;
 	w.ES = (long)NT * C * MAX_PLANES + 16;
 	w.TS = ((long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8 + 63) / 64 * 64;   // multiple of 64: every image's token arrays start vector-aligned
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
@@ -2085,8 +2159,9 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 
 	// carve scratch
 	{
-		size_t b = sizeof(unsigned short) * (size_t)nplanes * NT * NCUM;
-		w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b);
+		size_t b = align_up(sizeof(unsigned short) * (size_t)nplanes * NT * NCUM, 256);
+		w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b + (size_t)nplanes * w.NTP);
+		w.tile_top = (unsigned char *)w.cum + b;
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 		const size_t o_info = take(sizeof(ImgInfo) * n);
@@ -2099,6 +2174,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		const size_t o_ss = take(sizeof(unsigned long long) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_bt = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_sx = take(sizeof(int) * (size_t)n * 48 * MAX_PLANES);
+		const size_t o_lv = take(sizeof(unsigned) * (size_t)n * 48);
 		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
 		if (!w.cum || !small)
 			return DWTX_ERR_NOMEM;
@@ -2112,6 +2188,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.seg_stage = (unsigned long long *)(small + o_ss);
 		w.brk_tok = (unsigned *)(small + o_bt);
 		w.segidx = (int *)(small + o_sx);
+		w.live = (unsigned *)(small + o_lv);
 		DWTX_HIP(hipMemsetAsync(small, 0, o_sd, ctx->stream));
 		if (ctx->opt[DWTX_OPT_EXACT_ORDERS])   // test hook: take the hierarchical 32-state pass for every image
 			DWTX_HIP(hipMemsetAsync(small + o_slow, 1, sizeof(int) * n, ctx->stream));
@@ -2182,6 +2259,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
+	hipLaunchKernelGGL(k_cut, dim3(n), dim3(ENT_BLOCK), 0, s, w, capacity, (int)(ctx->opt[DWTX_OPT_NO_CAPACITY_CUT] != 0));
 	hipLaunchKernelGGL(k_stage_zero, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_code<false>, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_code<true>, dim3(dwtx_cdiv(NT, 4) < 64 ? dwtx_cdiv(NT, 4) : 64, nplanes), dim3(256), 0, s, g, lin, w);

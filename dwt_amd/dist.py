@@ -24,10 +24,11 @@ class StreamGather:
     Step k calls post(k, streams, lens) right after its encode: the byte lengths of all ranks are
     exchanged with one all_gather (8 bytes per frame) and copied to page-locked host memory without
     waiting.  collect(k) — called a step later, or at the end of the run — reads those lengths (the
-    copy finished long ago, so the host does not stall on the device inside a step), cuts the rows
-    to the longest stream of the whole job (rounded up to 8 bytes) and starts ONE gather of
-    [n, width] rows to `dst`; it overlaps whatever the caller runs next.  wait(k) orders the
-    caller's stream behind that gather, after which slot k % slots may be reused.
+    copy finished long ago, so the host does not stall on the device inside a step) and starts ONE
+    group of point-to-point transfers: every stream travels with its own length straight from the
+    encoder's output buffer into a row of `dst`'s slot (rows as wide as the step's longest stream);
+    it overlaps whatever the caller runs next.  wait(k) orders the caller's stream behind that
+    gather, after which slot k % slots may be reused.
 
     Rank `dst` keeps `slots` receive buffers of world x n x width bytes (grow-only): memory on the
     root is bounded by the step size, not by the length of the job — a consumer drains
@@ -76,7 +77,11 @@ class StreamGather:
             self.lens_ready[s] = ev
 
     def collect(self, k):
-        """Start the gather of step k's streams (post(k) must have been called)."""
+        """Start the gather of step k's streams (post(k) must have been called): every rank sends each of its
+        streams straight out of the encoder's buffer (row i, its own length rounded up to 8 bytes — a contiguous
+        view, nothing is copied or padded on the sender), rank `dst` receives them into rows of its slot; all
+        sends and receives of the step go out as ONE group (grouped ncclSend/ncclRecv on RCCL: the peers' links into
+        `dst` work side by side)."""
         torch, dist = self.torch, self.dist
         if k <= self.collected:
             return
@@ -85,40 +90,59 @@ class StreamGather:
         if self.lens_ready[s] is not None:
             self.lens_ready[s].synchronize()
         streams = self.streams[s]
-        width = min(streams.shape[1], _round8(self.all_lens_host[s].max()))
+        lens_all = self.all_lens_host[s].tolist()
+        n = self.n
+        width = min(streams.shape[1], _round8(max(lens_all)))
         self.width[s] = width
-        mine = streams[:, :width].to(self.cdev).contiguous()
-        self.send[s] = mine
-        bufs = None
+        ops, keep = [], []
         if self.rank == self.dst:
-            need = self.n * width
-            bufs = []
+            need = n * width
             for r in range(self.world):
                 flat = self.recv[s][r]
                 if flat is None or flat.numel() < need:
                     flat = torch.empty((need + need // 8,), dtype=torch.uint8, device=self.cdev)
                     self.recv[s][r] = flat
-                bufs.append(flat[:need].view(self.n, width))
-            self.bytes_gathered += int(self.all_lens_host[s].sum())
-        self.work[s] = dist.gather(mine, bufs, dst=self.dst, group=self.group, async_op=True)
+                rows = flat[:need].view(n, width)
+                if r == self.rank:
+                    rows.copy_(streams[:, :width])   # dst's own streams: one strided copy into its slot
+                    continue
+                for i in range(n):
+                    length = min(_round8(lens_all[r * n + i]), width)
+                    if length:
+                        ops.append(dist.P2POp(dist.irecv, rows[i, :length], r, self.group))
+            self.bytes_gathered += int(sum(lens_all))
+        else:
+            for i in range(n):
+                length = min(_round8(lens_all[self.rank * n + i]), width)
+                if length:
+                    row = streams[i, :length]
+                    if self.host_staged:   # gloo moves host memory only
+                        row = row.cpu()
+                        keep.append(row)
+                    ops.append(dist.P2POp(dist.isend, row, self.dst, self.group))
+        self.send[s] = keep
+        self.work[s] = dist.batch_isend_irecv(ops) if ops else []
 
     def wait(self, k):
         if k < 0:
             return
         s = k % self.slots
         if self.work[s] is not None:
-            self.work[s].wait()
+            for w in self.work[s]:
+                w.wait()
             self.work[s] = None
             self.send[s] = None
 
     def result(self, k):
-        """On dst: (list of per-rank uint8 [n, width] tensors, int64 host tensor [world*n] of byte lengths) of step k."""
+        """On dst: (list of per-rank uint8 [n, width] tensors — views of slot k % slots, valid until post(k + slots) —
+        and an int64 host tensor [world*n] of byte lengths, a copy) of step k."""
         s = k % self.slots
         self.wait(k)
+        lens = self.all_lens_host[s].clone()
         if self.rank != self.dst:
-            return None, self.all_lens_host[s]
+            return None, lens
         need = self.n * self.width[s]
-        return [self.recv[s][r][:need].view(self.n, self.width[s]) for r in range(self.world)], self.all_lens_host[s]
+        return [self.recv[s][r][:need].view(self.n, self.width[s]) for r in range(self.world)], lens
 
 
 def gather_streams(streams, lens, dst=0, group=None):
@@ -130,5 +154,4 @@ def gather_streams(streams, lens, dst=0, group=None):
     g = StreamGather(lens.numel(), streams.device, dst=dst, group=group, slots=1)
     g.post(0, streams, lens)
     g.collect(0)
-    bufs, all_lens = g.result(0)
-    return bufs, all_lens.clone()
+    return g.result(0)

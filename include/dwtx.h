@@ -66,14 +66,14 @@ typedef struct dwtx_stats {
 typedef struct dwtx_stream_info {
 	int planes[3];                 /* encode.c:163-165 */
 	int pmax;
-	int segments;                  /* (channel, level, plane) segments in the schedule, encode.c:183-221 */
+	int segments;                  /* (channel, level, plane) segments coded, encode.c:183-221 (all of the schedule unless CAPACITY cut it) */
 	int entries;
 	unsigned tokens;               /* VLI token slots (incl. void ones) */
 	int order0;                    /* VLI order after header, root image and plane counts */
 	unsigned hdr_bits;             /* 48 header bits + root image + plane counts */
 	unsigned root_bits;            /* encode.c:179-180, as the reference counts it (CAPACITY can cut into the root image) */
 	unsigned meta_bits;            /* encode.c:175-176: 48 unless CAPACITY < 6 */
-	unsigned reserved0;
+	unsigned segments_cut;         /* segments of the schedule left uncoded because they start beyond CAPACITY (encode.c:192,204,216) */
 	unsigned long long total_bits; /* encode.c:226: bit count before padding (8*capacity when truncated) */
 	unsigned long long nbytes;     /* bytes of the .dwt stream: min(capacity, ceil(total_bits/8)) */
 	int error;                     /* non-zero: unsupported data (more than 16 bit planes) */

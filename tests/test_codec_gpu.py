@@ -47,6 +47,33 @@ def test_config_d_16384_rgb_truncated_to_1mib(ctx):
     assert h.hexdigest() == rec["dec_sha256"]
 
 
+@pytest.mark.parametrize("shape", [(512, 512, 3), (1000, 700, 1), (2048, 1024, 3)])
+def test_capacity_stops_the_work_and_keeps_the_bytes(ctx, shape, opts):
+    """encode.c:192,204,216 leave the plane loop at the first refused byte: with a CAPACITY the encoder drops every
+    segment that cannot start inside it (pack.hip k_cut; dwtx_stream_info.segments_cut says how many) and the
+    bytes stay the exact prefix — the same bytes as with the cut switched off, and as the oracle's."""
+    import ctypes
+    import dwt_amd
+
+    W, H, Cn = shape
+    pix = ctx.synth_pixels(1, H, W, Cn, seed0=3, kind=0)
+    full, _ = orc.encode(pix[0].cpu().numpy())
+    cuts_seen = []
+    for cap in (64, 700, len(full) // 50, len(full) // 7, len(full) // 2, len(full) - 3, len(full), len(full) + 100):
+        got = {}
+        for off in (0, 1):
+            opts.set("no_capacity_cut", off)
+            streams, info = ctx.encode_device(pix, capacity=cap)
+            rec = dwt_amd.StreamInfo.from_buffer_copy(info[0].cpu().numpy().tobytes())
+            got[off] = (streams[0, : rec.nbytes].cpu().numpy().tobytes(), rec)
+        assert got[0][0] == got[1][0] == full[:cap], cap
+        assert got[1][1].segments_cut == 0
+        assert got[0][1].segments + got[0][1].segments_cut == got[1][1].segments
+        assert (got[0][1].total_bits, got[0][1].nbytes) == (got[1][1].total_bits, got[1][1].nbytes)
+        cuts_seen.append(got[0][1].segments_cut)
+    assert cuts_seen[0] > cuts_seen[3] > 0 and cuts_seen[-1] == 0 and cuts_seen[-2] == 0   # the tighter the capacity, the more is dropped
+
+
 def test_config_d_16384_rgb_whole_stream(ctx):
     """The same 805 M-sample frame without a capacity: 3 Gbit of stream (bit positions beyond 2^31), its first
     MiB is the reference's CAPACITY=1 MiB output (truncation yields a prefix), and it decodes

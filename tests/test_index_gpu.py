@@ -90,9 +90,15 @@ def test_a_wrong_index_changes_nothing(ctx, opts):
         elif kind == "beyond":
             for k in range(bad[1].nsegs):
                 bad[1].seg[k].bit = (1 << 40) + k
+        elif kind == "symbase_wraps":      # sym_base + ring size wraps around 2^64: the bound must not be checked with a sum
+            bad[0].seg[made[0].nsegs // 3].sym_base = 2 ** 64 - 40
+        elif kind == "symbase_past_the_bitmap":
+            bad[2].seg[made[2].nsegs // 2].sym_base = 1 << 45
+        elif kind == "order_32":           # an entry order only a damaged stream's serial walk can reach
+            bad[3].seg[made[3].nsegs // 2].order = 32
         return bad
 
-    for kind in ("foreign", "bit", "order", "n1", "short", "garbage", "beyond"):
+    for kind in ("foreign", "bit", "order", "n1", "short", "garbage", "beyond", "symbase_wraps", "symbase_past_the_bitmap", "order_32"):
         ctx.set_index(damaged(kind), 0)
         got, ginfos = _decode(ctx, streams, W, H, Cn)
         assert (got == want).all(), kind
