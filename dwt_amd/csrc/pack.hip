@@ -843,10 +843,10 @@ constexpr int TABP = 18;             // dwords per lane in the class table (9 pa
 constexpr int ROWW = 34;             // words per staging row of one plane (31 + 1024 bits + slack)
 
 struct alignas(16) CodeLds {
-	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1] | (t-1) << 12,  first slot of plane t-1 + Z[t] - Z[t-1] };
+	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1],  first slot of plane t-1 + Z[t] - Z[t-1] };
 	                                 // more: [lane][t-1] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
 	union {                          // (the token slots have left for memory before the refinement rows are gathered)
-		unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 10 | plane << 12
+		unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 12, then turned into tokens in place
 		unsigned rows[(MAX_PLANES - 1) * ROWW];
 	};
 	unsigned short cum[MAX_PLANES + 2];   // the tile's histogram: #(t <= q), q = 0..16
@@ -870,10 +870,54 @@ struct Nib<16> {
 	static constexpr T ONES = 0x1111111111111111ull, M0F = 0x0f0f0f0f0f0f0f0full;
 };
 
-template <int NQ, bool FULL>
-__device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], const Work &w, int img, int lane, int nvalid, int nv, int vb,
-	int P, unsigned my_tokbase, int my_ent, unsigned long long my_rb)
+// Bit transpose of eight bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte p holds bit p of the eight inputs,
+// input j at bit j.
+__device__ __forceinline__ void transpose8(unsigned &lo, unsigned &hi)
 {
+	unsigned t;
+	t = (lo ^ (lo >> 7)) & 0x00AA00AAu;
+	lo ^= t ^ (t << 7);
+	t = (hi ^ (hi >> 7)) & 0x00AA00AAu;
+	hi ^= t ^ (t << 7);
+	t = (lo ^ (lo >> 14)) & 0x0000CCCCu;
+	lo ^= t ^ (t << 14);
+	t = (hi ^ (hi >> 14)) & 0x0000CCCCu;
+	hi ^= t ^ (t << 14);
+	const unsigned nlo = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);
+	hi = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);
+	lo = nlo;
+}
+
+// PEXT4[mask << 4 | bits]: the bits that stand on the set positions of a 4-bit mask, pushed together (entry i is
+// computed by thread i of the workgroup).  256 bytes: every LDS bank holds one word of it, look-ups never conflict.
+__device__ __forceinline__ unsigned pext4_entry(unsigned i)
+{
+	const unsigned m = i >> 4, v = i & 15u;
+	unsigned out = 0, k = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		out |= (((v & m) >> j) & 1u) << k;
+		k += (m >> j) & 1u;
+	}
+	return out;
+}
+
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+// two token slots at once: zero count minus the predecessor's (low 10 bits of each half), the sign bit (12) stays
+__device__ __forceinline__ unsigned slots_to_tokens(unsigned a, unsigned before)
+{
+	const unsigned b = __builtin_amdgcn_alignbit(a, before, 16);   // the slots one place earlier
+	const ushort2_t d = __builtin_bit_cast(ushort2_t, a & 0x03ff03ffu) - __builtin_bit_cast(ushort2_t, b & 0x03ff03ffu);
+	return (a & 0x10001000u) | __builtin_bit_cast(unsigned, d);
+}
+
+template <int NQ, bool FULL>
+__device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4, const int (&val)[16], const Work &w, int img, int lane, int nvalid,
+	int nv, int vb, int Pc, int tile_top, unsigned my_tokbase, int my_ent, unsigned long long my_rb)
+{
+	// Planes at or above the tile's own bit-plane count hold nothing but zeros here: all per-class work stops at P
+	const int P = Pc < tile_top ? Pc : tile_top;
 	typedef typename Nib<NQ>::T R_t;
 	constexpr R_t ONES = Nib<NQ>::ONES, M0F = Nib<NQ>::M0F;
 	constexpr int NB = NQ / 4;   // dwords of 16-bit fields per parity
@@ -926,11 +970,10 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	for (int t = 1; t <= NQ; ++t) {
 		if (t <= P) {
 			const unsigned zlo = ZL(t - 1);
-			const unsigned zhi = t < NQ ? ZL(t) : (unsigned)vb;
-			const unsigned ct = t < NQ ? CT(t) : (unsigned)nvalid;
+			const unsigned zhi = t < NQ && t < P ? ZL(t) : (unsigned)vb;   // (no coefficient of this tile has more than P bits)
+			const unsigned ct = t < NQ && t < P ? CT(t) : (unsigned)nvalid;
 			if (NQ == 8)
-				*reinterpret_cast<uint2 *>(&L.tab[lane * TABP + 2 * (t - 1)]) =
-					make_uint2(zlo | (unsigned)(t - 1) << 12, (unsigned)nvalid - ct + zhi - zlo);
+				*reinterpret_cast<uint2 *>(&L.tab[lane * TABP + 2 * (t - 1)]) = make_uint2(zlo, (unsigned)nvalid - ct + zhi - zlo);
 			else
 				L.tab[lane * TABP + t - 1] = zlo | (zhi - zlo) << 10 | ((unsigned)nvalid - ct) << 20;
 		}
@@ -958,7 +1001,7 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 					ent[i % NB8] = *reinterpret_cast<const uint2 *>(&L.tab[lane * TABP + 2 * tm]);
 				} else {
 					const unsigned e = L.tab[lane * TABP + tm];
-					ent[i % NB8] = make_uint2((e & 0x3ffu) | (unsigned)tm << 12, (e >> 20) + ((e >> 10) & 0x3ffu));
+					ent[i % NB8] = make_uint2(e & 0x3ffu, (e >> 20) + ((e >> 10) & 0x3ffu));
 				}
 			}
 #pragma unroll
@@ -969,7 +1012,7 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 				const unsigned lz_lo = x & 15u;
 				const unsigned lz_hi = t < NQ ? (x >> 4) & 15u : (unsigned)i;
 				const unsigned slot = mag[i] ? ent[i % NB8].y + lz_hi - lz_lo : (unsigned)(TILE + (lane & 7));
-				L.zs[slot] = (unsigned short)(ent[i % NB8].x + lz_lo + ((sgn >> i) & 1u) * 0x400u);
+				L.zs[slot] = (unsigned short)(ent[i % NB8].x + lz_lo + ((sgn >> i) & 1u) * 0x1000u);
 				const int te = FULL || i < nv ? t : NQ;
 				R += te < NQ ? ONES << (4 * te) : (R_t)0;
 			}
@@ -983,9 +1026,43 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	}
 	wave_sync();
 
-	// ---- tokens out, plane by plane (a plane's tokens are consecutive slots and consecutive in the stream):
-	//      run = zeros since the previous one of the same plane in this tile ----
+	// ---- tokens: run = zeros since the previous one of the same plane in this tile = a slot's zero count minus its
+	//      predecessor's; the first slot of a plane keeps its count.  Eight slots per lane at a time, two per instruction,
+	//      in place; then every plane's tokens — consecutive slots, consecutive in the stream — leave as they are ----
 	{
+		// (lanes 0..15 take a plane each) the plane's first slot as it is, and the zeros after its last one: what the
+		// tile hands to the run counter (k_carry_*)
+		unsigned first_tok = 0;
+		int first_slot = -1;
+		if (lane < MAX_PLANES) {
+			const int p = lane;
+			const unsigned c0 = L.cum[p], c1 = L.cum[p + 1];
+			const unsigned ones = c1 - c0, slot0 = (unsigned)nvalid - c1;
+			if (ones) {
+				first_slot = (int)slot0;
+				first_tok = L.zs[slot0];
+			}
+			if (L.ent[p] >= 0)
+				w.ent_tz[img * w.ES + L.ent[p]] = (unsigned short)(ones ? c0 - (L.zs[slot0 + ones - 1] & 0x3ffu) : c0);
+		}
+		const int nslots = nvalid - (int)L.cum[0];   // the tile's non-zero coefficients
+		uint4 *zq = reinterpret_cast<uint4 *>(L.zs);
+		uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = a0;
+		unsigned before0 = 0, before1 = 0;
+		a0 = zq[lane];
+		before0 = lane ? (unsigned)L.zs[8 * lane - 1] << 16 : 0u;
+		if (nslots > 512) {   // uniform
+			a1 = zq[64 + lane];
+			before1 = (unsigned)L.zs[512 + 8 * lane - 1] << 16;
+		}
+		wave_sync();
+		zq[lane] = make_uint4(slots_to_tokens(a0.x, before0), slots_to_tokens(a0.y, a0.x), slots_to_tokens(a0.z, a0.y), slots_to_tokens(a0.w, a0.z));
+		if (nslots > 512)
+			zq[64 + lane] = make_uint4(slots_to_tokens(a1.x, before1), slots_to_tokens(a1.y, a1.x), slots_to_tokens(a1.z, a1.y), slots_to_tokens(a1.w, a1.z));
+		wave_sync();
+		if (first_slot >= 0)
+			L.zs[first_slot] = (unsigned short)first_tok;
+		wave_sync();
 		unsigned short *tok16 = w.tok16 + img * w.TS;
 		for (int p = P > 0 ? P - 1 : 0; p >= 0; --p) {
 			const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p]), c1 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p + 1]);
@@ -995,26 +1072,9 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 				continue;   // uniform
 			const int slot0 = nvalid - (int)c1;
 			unsigned short *dst = tok16 + gb + (unsigned)slot0;
-			unsigned carry = 0;   // the slot before this round's first one
-			for (int k0 = 0; k0 < ones; k0 += 64) {
-				const int k = k0 + lane;
-				const unsigned a = k < ones ? L.zs[slot0 + k] : 0u;
-				const unsigned b = (unsigned)__builtin_amdgcn_update_dpp((int)carry, (int)a, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps carry
-				carry = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
-				if (k < ones) {
-					const unsigned z = a & 0x3ffu;
-					const unsigned run = k ? z - (b & 0x3ffu) : z;
-					dst[k] = (unsigned short)(run | ((a >> 10) & 1u) << 12);
-				}
-			}
-		}
-		// zeros after the tile's last one of each plane: what the tile hands to the run counter (k_carry_*)
-		if (lane < MAX_PLANES && L.ent[lane] >= 0) {
-			const int p = lane;
-			const unsigned c0 = L.cum[p], c1 = L.cum[p + 1];
-			const unsigned ones = c1 - c0, slot0 = (unsigned)nvalid - c1;
-			const unsigned tz = ones ? c0 - (L.zs[slot0 + ones - 1] & 0x3ffu) : c0;
-			w.ent_tz[img * w.ES + L.ent[p]] = (unsigned short)tz;
+			const unsigned short *src = L.zs + slot0;
+			for (int k = lane; k < ones; k += 64)
+				dst[k] = src[k];
 		}
 	}
 
@@ -1023,18 +1083,8 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 	for (int i = lane; i < (MAX_PLANES - 1) * ROWW; i += 64)
 		L.rows[i] = 0u;
 	wave_sync();
-	for (int p = P - 2; p >= 0; --p) {
-		const int refs = nvalid - (int)L.cum[p + 1];
-		if (refs <= 0 || L.ent[p] < 0)
-			continue;   // uniform
-		const unsigned thr = 2u << p;
-		unsigned acc = 0, cnt = 0;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const bool isref = mag[i] >= thr;
-			acc |= (isref ? (mag[i] >> p) & 1u : 0u) << cnt;
-			cnt += isref ? 1u : 0u;
-		}
+	// the lane's string of plane p at its place in the plane's row
+	auto deposit = [&](int p, unsigned acc, unsigned cnt) {
 		const unsigned zl = L.tab[lane * TABP + (NQ == 8 ? 2 : 1) * (p + 1)] & 0x3ffu;   // Z[p+1] of the lanes before
 		const unsigned pos = (unsigned)(L.rb[p] & 31ull) + ((unsigned)vb - zl);
 		if (cnt) {
@@ -1043,6 +1093,50 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 			atomicOr(&row[pos >> 5], acc << sh);
 			if (sh + cnt > 32u)
 				atomicOr(&row[(pos >> 5) + 1], acc >> (32u - sh));
+		}
+	};
+	if (NQ == 8) {
+		// Magnitudes below 256: the 16 of them as bytes, bit-transposed, are the lane's sixteen bits of every plane
+		// at once (byte p of A: coefficients 0..7, of B: 8..15).  A coefficient takes part in plane p's refinement
+		// pass if a higher plane has a bit of it: the OR of the bytes above.  The string is the plane's bits on those
+		// positions pushed together, a nibble per table look-up (PEXT4).
+		unsigned A0 = mag[0] | mag[1] << 8 | mag[2] << 16 | mag[3] << 24, A1 = mag[4] | mag[5] << 8 | mag[6] << 16 | mag[7] << 24;
+		unsigned B0 = mag[8] | mag[9] << 8 | mag[10] << 16 | mag[11] << 24, B1 = mag[12] | mag[13] << 8 | mag[14] << 16 | mag[15] << 24;
+		transpose8(A0, A1);
+		transpose8(B0, B1);
+		const unsigned SA1 = (A1 >> 8) | (A1 >> 16) | (A1 >> 24), SB1 = (B1 >> 8) | (B1 >> 16) | (B1 >> 24);
+		const unsigned SA0 = (A0 >> 8) | (A0 >> 16) | (A0 >> 24) | ((SA1 | A1) & 0xffu) * 0x01010101u;
+		const unsigned SB0 = (B0 >> 8) | (B0 >> 16) | (B0 >> 24) | ((SB1 | B1) & 0xffu) * 0x01010101u;
+		auto plane_string = [&](int p, unsigned Aw, unsigned SAw, unsigned Bw, unsigned SBw) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				return;   // uniform
+			const unsigned sh8 = 8u * ((unsigned)p & 3u);
+			const unsigned nA = (Aw >> sh8) & 0xffu, sA = (SAw >> sh8) & 0xffu, nB = (Bw >> sh8) & 0xffu, sB = (SBw >> sh8) & 0xffu;
+			const unsigned e0 = pext4[((sA & 15u) << 4) | (nA & 15u)], e1 = pext4[(sA & 0xf0u) | (nA >> 4)];
+			const unsigned e2 = pext4[((sB & 15u) << 4) | (nB & 15u)], e3 = pext4[(sB & 0xf0u) | (nB >> 4)];
+			const unsigned c0 = (unsigned)__builtin_popcount(sA & 15u), c1 = (unsigned)__builtin_popcount(sA);
+			const unsigned c2 = c1 + (unsigned)__builtin_popcount(sB & 15u), c3 = c1 + (unsigned)__builtin_popcount(sB);
+			deposit(p, e0 | e1 << c0 | e2 << c1 | e3 << c2, c3);
+		};
+		for (int p = P - 2; p >= 4; --p)
+			plane_string(p, A1, SA1, B1, SB1);
+		for (int p = P - 2 < 3 ? P - 2 : 3; p >= 0; --p)
+			plane_string(p, A0, SA0, B0, SB0);
+	} else {
+		for (int p = P - 2; p >= 0; --p) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				continue;   // uniform
+			const unsigned thr = 2u << p;
+			unsigned acc = 0, cnt = 0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const bool isref = mag[i] >= thr;
+				acc |= (isref ? (mag[i] >> p) & 1u : 0u) << cnt;
+				cnt += isref ? 1u : 0u;
+			}
+			deposit(p, acc, cnt);
 		}
 	}
 	wave_sync();
@@ -1073,7 +1167,8 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const int (&val)[16], cons
 // of four (its LDS fits five workgroups per CU since the refinement rows share the token slots' words).  The wide
 // variant runs a small grid that strides over the tiles, so that launching it for nothing costs nothing.
 template <bool WIDE>
-__device__ __forceinline__ void code_one(const PackGeom &g, const int *__restrict__ lin, const Work &w, CodeLds &L, int tile, int plane, int lane)
+__device__ __forceinline__ void code_one(const PackGeom &g, const int *__restrict__ lin, const Work &w, CodeLds &L, const unsigned char *pext4, int tile,
+	int plane, int lane)
 {
 	const int img = plane / g.C, c = plane - img * g.C;
 	const ImgInfo &I = w.info[img];
@@ -1127,11 +1222,11 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	}
 	if (!WIDE) {
 		if (nvalid == TILE)
-			code_tile<8, true>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+			code_tile<8, true>(L, pext4, val, w, img, lane, nvalid, nv, vb, P, tile_top, my_tokbase, my_ent, my_rb);
 		else
-			code_tile<8, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+			code_tile<8, false>(L, pext4, val, w, img, lane, nvalid, nv, vb, P, tile_top, my_tokbase, my_ent, my_rb);
 	} else {
-		code_tile<16, false>(L, val, w, img, lane, nvalid, nv, vb, P, my_tokbase, my_ent, my_rb);
+		code_tile<16, false>(L, pext4, val, w, img, lane, nvalid, nv, vb, P, tile_top, my_tokbase, my_ent, my_rb);
 	}
 	}
 }
@@ -1140,18 +1235,21 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
 {
 	__shared__ CodeLds lds[4];
+	__shared__ unsigned char pext4[256];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int plane = blockIdx.y;
 	const int img = plane / g.C, c = plane - img * g.C;
 	if ((w.info[img].planes[c] > 8) != WIDE)
 		return;   // (uniform over the workgroup) the other kernel's plane
 	if (!WIDE) {
+		pext4[threadIdx.x] = (unsigned char)pext4_entry(threadIdx.x);
+		__syncthreads();   // the only point where the workgroup's waves meet
 		const int tile = blockIdx.x * 4 + wv;
 		if (tile < w.NT)   // whole wave; nothing below synchronises across waves
-			code_one<false>(g, lin, w, lds[wv], tile, plane, lane);
+			code_one<false>(g, lin, w, lds[wv], pext4, tile, plane, lane);
 	} else {
 		for (int tile = blockIdx.x * 4 + wv; tile < w.NT; tile += gridDim.x * 4) {
-			code_one<true>(g, lin, w, lds[wv], tile, plane, lane);
+			code_one<true>(g, lin, w, lds[wv], pext4, tile, plane, lane);
 			wave_sync();   // the wave's next tile reuses its LDS
 		}
 	}
