@@ -38,16 +38,17 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
     "gray4096": (4096, 4096, 1, 64),
-    "rgb1080p": (1920, 1080, 3, 256),   # (configs[2] is 1024 frames: the decoder's per-image token walk hides behind batches from about 256 on)
+    "rgb1080p": (1920, 1080, 3, 1024),  # configs[2]: 1024 frames per step, 6.4 G samples in one call each way
     "rgb4096": (4096, 4096, 3, 32),
 }
 CONFIG_OF = {
     "gray4096": "BASELINE.json configs[1] geometry",
-    "rgb1080p": "BASELINE.json configs[2] geometry",
+    "rgb1080p": "BASELINE.json configs[2]",
     "rgb4096": "BASELINE.json configs[4] geometry",
 }
 GOLDEN_OF = {"gray4096": "g4096x4096", "rgb1080p": "c1920x1080", "rgb4096": "c4096x4096"}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave64 vector instructions per second: 256 CUs x 4 SIMD16 x 2.4 GHz, four cycles per wave64 instruction
 LIFT_BYTES_PER_SAMPLE = 16      # int32 read + write, forward and inverse
 LIFT_READ_BYTES_PER_SAMPLE = 8  # the read-only variant
 
@@ -197,7 +198,71 @@ def coder_record(ctx, torch, dwt_amd, lin, W, H, C, B, stride, dev, reps=2):
     for name, ms in best.items():
         rec[name] = {"ms_per_step": round(ms, 3), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
                      "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # The stage is bound by vector-instruction issue, not by memory: its instruction roofline.  The per-kernel
+    # instruction counts cannot be read from inside this process; they come from the committed rocprofv3 --pmc
+    # run over the same kernels (tools/pmc_coder.sh -> profiles/*_coder_insts.json: SQ_INSTS_VALU and SQ_WAVES per
+    # kernel for one encode + decode of 4096x4096 gray frames), scaled by the coefficient count; the time is this run's.
+    ipath = os.path.join(ROOT, "profiles", "r03_coder_insts.json")
+    if os.path.exists(ipath) and (W, H, C) == (4096, 4096, 1):
+        ij = json.load(open(ipath))
+        for name in ("encode", "decode"):
+            per_coef = ij[name]["valu_wave_insts_per_coefficient"]     # wave64 instructions per coefficient (x 64 = lane operations)
+            insts = per_coef * samples
+            rec[name]["valu_insts_per_coefficient"] = round(per_coef * 64, 1)   # vector operations per coefficient (64 lanes per wave instruction)
+            rec[name]["frac_of_valu_issue_peak"] = round(insts / (rec[name]["ms_per_step"] * 1e-3) / VALU_ISSUE_PEAK, 4)
+        rec["instruction_roofline"] = {"peak_wave_insts_per_s": VALU_ISSUE_PEAK, "source": "profiles/r03_coder_insts.json",
+                                       "per_kernel": ij.get("per_kernel")}
     return rec
+
+
+def capacity_record(dwt_amd, torch, local, timed):
+    """BASELINE.json configs[3]: one 16384x16384 RGB frame with CAPACITY = 1 MiB (encode.c:150-152,192-217): encode with the
+    capacity cut (pack.hip k_cut: segments that start beyond the capacity are never coded) and with the cut switched off
+    (everything coded, the stream clipped at the end), decode of the 1 MiB stream, the reference's hashes."""
+    W = H = 16384
+    C, cap = 3, 1 << 20
+    cx = dwt_amd.Context(local)
+    try:
+        pix = cx.synth_pixels(1, H, W, C, 0, 0)
+        stride = (cap + 15) // 8 * 8
+        streams = torch.empty((1, stride), dtype=torch.uint8, device=pix.device)
+        info = torch.empty((1, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=pix.device)
+        rec = {"workload": "one 16384x16384x3 frame, CAPACITY 1048576 (BASELINE.json configs[3])"}
+        shas = {}
+        for name, off in (("encode_ms", 0), ("encode_ms_all_segments_coded", 1)):
+            cx.set_option("no_capacity_cut", off)
+            cx.encode_device(pix, capacity=cap, out=streams, info=info)
+            torch.cuda.synchronize()
+            si = dwt_amd.StreamInfo.from_buffer_copy(info[0].cpu().numpy().tobytes())
+            shas[name] = hashlib.sha256(streams[0, : si.nbytes].cpu().numpy().tobytes()).hexdigest()
+            rec[name] = round(min(timed(lambda: cx.encode_device(pix, capacity=cap, out=streams, info=info))[0] for _ in range(3)), 3)
+            if not off:
+                rec["bytes"], rec["segments_coded"], rec["segments_cut"] = int(si.nbytes), int(si.segments), int(si.segments_cut)
+        cx.set_option("no_capacity_cut", 0)
+        cx.encode_device(pix, capacity=cap, out=streams, info=info)
+        lens = cx.stream_lengths(info)
+        out = torch.empty((1, W * H * C), dtype=torch.uint8, device=pix.device)
+        _, dinfos = cx.decode_device(streams, lens, W, H, C, out=out)
+        rec["decode_ms"] = round(min(timed(lambda: cx.decode_device(streams, lens, W, H, C, out=out))[0] for _ in range(3)), 3)
+        gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
+        if os.path.exists(gpath):
+            g = json.load(open(gpath)).get("c16384x16384_cap1MiB")
+            if g:
+                geo = dwt_amd.geometry(W, H)
+                lo = dinfos[0].level + 1
+                ow, oh = geo.widths[lo], geo.heights[lo]
+                h = hashlib.sha256()
+                flat = out[0, : ow * oh * C]
+                for i in range(0, flat.numel(), 1 << 27):
+                    h.update(flat[i:i + (1 << 27)].cpu().numpy().tobytes())
+                rec["stream_matches_reference_golden"] = shas["encode_ms"] == g["dwt_sha256"] == shas["encode_ms_all_segments_coded"]
+                rec["decoded_picture_matches_reference_golden"] = (ow, oh) == (g["dec_W"], g["dec_H"]) and h.hexdigest() == g["dec_sha256"]
+        rec["Mpixels_per_s_roundtrip"] = round(W * H / ((rec["encode_ms"] + rec["decode_ms"]) * 1e-3) / 1e6, 1)
+        rec["note"] = ("the floor of this encode is the part CAPACITY cannot cut: the whole forward transform and one pass over all "
+                       "coefficients for the plane counts (encode.c:159-165 run in full in the reference too)")
+        return rec
+    finally:
+        cx.close()
 
 
 def golden_check(name, stream0):
@@ -482,7 +547,17 @@ def main():
             # a context of its own: scratch sized and placed for this workload, as when it is the main one (inside the
             # scratch the gray batch left behind, 16 frames of 4096x4096 RGB ran anywhere between 18.5 and 27 ms per step)
             cx = dwt_amd.Context(local)
-            r2 = Runner(cx, torch, dwt_amd, name, 0, 0, 1, dev)
+            try:
+                r2 = Runner(cx, torch, dwt_amd, name, 0, 0, 1, dev)
+                r2.step()   # (sizes every scratch buffer)
+                torch.cuda.synchronize()
+            except (RuntimeError, MemoryError) as err:   # the configuration's full batch does not fit beside what else lives on this GPU: a quarter of it
+                r2 = None
+                torch.cuda.empty_cache()
+                cx.close()
+                cx = dwt_amd.Context(local)
+                r2 = Runner(cx, torch, dwt_amd, name, max(1, WORKLOADS[name][3] // 4), 0, 1, dev)
+                CONFIG_OF[name] += f" at a quarter of its batch ({type(err).__name__} at the full one)"
             XS = 6   # steps of a side workload (2 warm-up steps: a 3-step run once caught a cold start and read 30 % low)
             t2, (s2, l2, d2, i2), _ = r2.timed(XS, 2, fence)
             ok2 = bool(torch.equal(d2.view(r2.B, r2.H, r2.W, r2.C), r2.pix)) and all(i.status == 0 and not i.truncated for i in i2)
@@ -506,6 +581,8 @@ def main():
             del r2, s2, d2
             cx.close()
             del cx
+        torch.cuda.empty_cache()
+        extras["rgb16384_cap1MiB"] = capacity_record(dwt_amd, torch, local, timed)
         result["workloads"] = extras
 
     if rank == 0:

@@ -18,14 +18,11 @@ extern "C" size_t dwtx_encode_bound(int W, int H, int C)
 	return (b + 7) / 8 * 8;
 }
 
-// pixels (device) -> streams (device); async on the context's stream
-extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int C, int n, long capacity,
-	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info)
+// pixels (device) -> streams (device) for one part of a batch, on the part's context; `lifted` (optional) is recorded
+// once the part's transform and linearisation are queued
+static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int C, int n, long capacity,
+	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info, hipEvent_t lifted)
 {
-	if (!ctx || !dev_pix || !dev_out || !dev_info || (C != 1 && C != 3) || n < 1)
-		return DWTX_ERR_ARG;
-	DWTX_ENTER(ctx);
-	DWTX_CHECK_DIMS(W, H);
 	const size_t bytes = sizeof(int) * (size_t)W * H * C * n;
 	int *a = (int *)dwtx_scratch(ctx, SLOT_CD_A, bytes);
 	int *b = (int *)dwtx_scratch(ctx, SLOT_CD_B, bytes);
@@ -45,7 +42,51 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 	const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
 	if ((rc = dwtx_linearization_ex(ctx, a, b, W, H, n * C, sq)))
 		return rc;
+	if (lifted)
+		DWTX_HIP(hipEventRecord(lifted, ctx->stream));
 	return dwtx_encode_planes_ex(ctx, a, b, sq, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
+}
+
+// pixels (device) -> streams (device); async on the context's stream.
+// The transform is bound by memory, the entropy stage by vector-instruction issue: a batch runs as parts on streams of
+// their own, staggered so that part k's transform runs beside part k-1's entropy stage (the transforms follow one
+// another: each fills the memory system by itself).  The caller's stream waits for all parts.
+extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int C, int n, long capacity,
+	uint8_t *dev_out, size_t out_stride, dwtx_stream_info *dev_info)
+{
+	if (!ctx || !dev_pix || !dev_out || !dev_info || (C != 1 && C != 3) || n < 1)
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	DWTX_CHECK_DIMS(W, H);
+	const int K = ctx->opt[DWTX_OPT_ONE_STREAM] || n < 2 * DWTX_ENC_PARTS ? 1 : DWTX_ENC_PARTS;
+	if (K == 1)
+		return encode_part(ctx, dev_pix, W, H, C, n, capacity, dev_out, out_stride, dev_info, nullptr);
+	dwtx_ctx *part[DWTX_ENC_PARTS];
+	int rc;
+	for (int k = 0; k < K; ++k)
+		if ((rc = dwtx_encoder_part(ctx, k, &part[k])))
+			return rc;
+	hipEvent_t *lifted = ctx->enc_ev, *done = ctx->enc_ev + DWTX_ENC_PARTS, start = ctx->enc_ev[2 * DWTX_ENC_PARTS];
+	DWTX_HIP(hipEventRecord(start, ctx->stream));   // the pixels are the caller's earlier work on its stream
+	const size_t img_bytes = (size_t)W * H * C;
+	rc = DWTX_OK;
+	int queued = 0;
+	for (int k = 0; k < K && !rc; ++k) {
+		const int i0 = (int)((long)n * k / K), cnt = (int)((long)n * (k + 1) / K) - i0;
+		hipStream_t st = part[k]->stream;
+		DWTX_HIP(hipStreamWaitEvent(st, start, 0));
+		if (k)
+			DWTX_HIP(hipStreamWaitEvent(st, lifted[k - 1], 0));
+		rc = encode_part(part[k], dev_pix + img_bytes * i0, W, H, C, cnt, capacity, dev_out + out_stride * (size_t)i0, out_stride,
+			dev_info + i0, lifted[k]);
+		if (hipEventRecord(done[k], st) != hipSuccess && !rc)
+			rc = DWTX_ERR_DEVICE;
+		queued = k + 1;
+	}
+	for (int k = 0; k < queued; ++k)   // (also after a failure: what was queued reads the caller's buffers)
+		if (hipStreamWaitEvent(ctx->stream, done[k], 0) != hipSuccess && !rc)
+			rc = DWTX_ERR_DEVICE;
+	return rc;
 }
 
 // streams (device) -> pixels (device).  Image i is written densely (ow*oh*C bytes)

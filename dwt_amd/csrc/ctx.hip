@@ -110,12 +110,58 @@ extern "C" int dwtx_ctx_set_index(dwtx_ctx *c, const dwtx_index *in, dwtx_index 
 	return DWTX_OK;
 }
 
+int dwtx_need_side_streams(dwtx_ctx *c, bool more)
+{
+	if (!c->have_aux) {
+		DWTX_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+		for (int i = 0; i < 4; ++i)
+			DWTX_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+		c->have_aux = true;
+	}
+	if (more && !c->have_more) {
+		for (int i = 0; i < 2; ++i)
+			DWTX_HIP(hipStreamCreateWithFlags(&c->more[i], hipStreamNonBlocking));
+		for (int i = 0; i < 8; ++i)
+			DWTX_HIP(hipEventCreateWithFlags(&c->pev[i], hipEventDisableTiming));
+		c->have_more = true;
+	}
+	return DWTX_OK;
+}
+
+int dwtx_encoder_part(dwtx_ctx *c, int k, dwtx_ctx **part)
+{
+	if (k < 0 || k >= DWTX_ENC_PARTS)
+		return DWTX_ERR_ARG;
+	if (!c->have_enc_ev) {
+		for (int i = 0; i < 2 * DWTX_ENC_PARTS + 1; ++i)
+			DWTX_HIP(hipEventCreateWithFlags(&c->enc_ev[i], hipEventDisableTiming));
+		c->have_enc_ev = true;
+	}
+	if (!c->enc_part[k]) {
+		int rc = dwtx_need_side_streams(c, true);
+		if (rc)
+			return rc;
+		hipStream_t st = k == 0 ? c->stream : k == 1 ? c->aux : c->more[k - 2];
+		if ((rc = ctx_create(c->device, (void *)st, false, &c->enc_part[k])))
+			return rc;
+	}
+	memcpy(c->enc_part[k]->opt, c->opt, sizeof(c->opt));
+	*part = c->enc_part[k];
+	return DWTX_OK;
+}
+
 extern "C" void dwtx_ctx_destroy(dwtx_ctx *c)
 {
 	if (!c)
 		return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	for (int k = 0; k < DWTX_ENC_PARTS; ++k)
+		if (c->enc_part[k])
+			dwtx_ctx_destroy(c->enc_part[k]);
+	if (c->have_enc_ev)
+		for (int i = 0; i < 2 * DWTX_ENC_PARTS + 1; ++i)
+			(void)hipEventDestroy(c->enc_ev[i]);
 	dwtx_free_plans(c);
 	for (int i = 0; i < DWTX_SCRATCH_SLOTS; ++i)
 		if (c->scratch[i])

@@ -7,6 +7,7 @@
 #include "../../include/dwtx.h"
 
 #define DWTX_SCRATCH_SLOTS 24
+#define DWTX_ENC_PARTS 4
 
 struct dwtx_linplan;
 
@@ -30,6 +31,11 @@ struct dwtx_ctx {
 	dwtx_index *index_out;
 	size_t index_base;            // entry of the current call's first image (the host pipeline decodes a batch in parts)
 	long opt[DWTX_OPT_COUNT];     // dwtx_ctx_set_option: diagnostic switches (tests, tools), all 0 by default
+	// dwtx_encode_device cuts a batch into parts that run on contexts of their own (stream + scratch each): one part's
+	// memory-bound lifting overlaps the instruction-bound entropy stage of the part before (codec.hip)
+	dwtx_ctx *enc_part[DWTX_ENC_PARTS];
+	hipEvent_t enc_ev[2 * DWTX_ENC_PARTS + 1];   // [k] part k's transform is queued, [PARTS + k] part k is done, [2 * PARTS] the call's start
+	bool have_enc_ev;
 };
 
 // Every entry point that allocates, launches or copies makes the context's device the calling thread's current
@@ -48,6 +54,11 @@ int dwtx_debug_check_device(dwtx_ctx *ctx, const char *file, int line);
 #endif
 
 void dwtx_free_plans(dwtx_ctx *ctx);
+int dwtx_need_side_streams(dwtx_ctx *ctx, bool more);            // ctx.hip: creates aux / ev (and more / pev) on first use
+// ctx.hip: part k's context (made on first use) with the parent's options.  Parts run on the context's own streams — the
+// caller's, aux, more[0], more[1]: the runtime maps streams onto a handful of hardware queues, and streams that share a
+// queue run one after the other; the encoder's and the decoder's parts therefore use the same four.
+int dwtx_encoder_part(dwtx_ctx *ctx, int k, dwtx_ctx **part);
 int dwtx_need_copy_stream(dwtx_ctx *ctx);   // creates ctx->copy / ctx->cev on first use
 
 void dwtx_set_error(const char *fmt, ...);

@@ -2200,11 +2200,10 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		DWTX_HIP(hipMemsetAsync(small, 0, o_zero_end, ctx->stream));
 		// The symbol bitmap (the one big clear, ~64 MB per 4096x4096 plane) is only needed by the token walk:
 		// it is cleared on the second stream while the chunk tables are built on the first.
-		if (!ctx->have_aux) {
-			DWTX_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-			for (int i = 0; i < 4; ++i)
-				DWTX_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
-			ctx->have_aux = true;
+		{
+			const int rc_side = dwtx_need_side_streams(ctx, false);
+			if (rc_side)
+				return rc_side;
 		}
 		DWTX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));            // earlier work on the main stream may still read the bitmap
 		DWTX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev[2], 0));
@@ -2427,13 +2426,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		part_first[k] = (int)((long)n * k / K);
 	for (int k = K + 1; k <= MAX_PARTS; ++k)
 		part_first[k] = 0;
-	if (K > 2 && !ctx->have_more) {
-		for (int i = 0; i < 2; ++i)
-			DWTX_HIP(hipStreamCreateWithFlags(&ctx->more[i], hipStreamNonBlocking));
-		for (int i = 0; i < 8; ++i)
-			DWTX_HIP(hipEventCreateWithFlags(&ctx->pev[i], hipEventDisableTiming));
-		ctx->have_more = true;
-	}
+	if (K > 2 && (rc = dwtx_need_side_streams(ctx, true)))
+		return rc;
 	auto stream_of = [&](int k) { return k == 0 ? s : k == 1 ? ctx->aux : ctx->more[k - 2]; };
 	auto run_parts = [&]() -> int {
 		for (int k = 0; k < K; ++k) {
