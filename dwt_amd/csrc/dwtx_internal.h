@@ -114,8 +114,23 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
 int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n);   // C = 3: YCoCg-R fused too (image.h:52-65)
 int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n);   // C = 3: image.h:39-50 fused too
 
-// Tiles straight from / to the pyramid (hilbert_dev.h): ring levels that are full power-of-two squares (bit l of the
-// mask) need no linearised copy — the entropy stage reads (pack.hip) / writes (unpack.hip) their 32x32 squares itself.
+// The entropy stage's tiles (linearize.hip): the Hilbert curve of ring level l visits every aligned 32x32 square of
+// its lengths[l+1]-sided square contiguously ("curve block"), so the ring's coefficients, in the order of
+// encode.c:46-56, are the blocks' points one block after the other.  A tile is one non-empty curve block: `base` =
+// ring index of its first coefficient, `cnt` = its coefficients (1024 for a block that lies wholly inside the ring),
+// `blk` = the block's index on the curve.  Levels below 32x32 are one block each.  Tiles are numbered level by level.
+struct dwtx_tiles {
+	int NT;
+	int tile_first[DWTX_MAX_LEVELS + 1];
+	const int *base;              // device, [NT]
+	const unsigned short *cnt;    // device, [NT]
+	const int *blk;               // device, [NT]
+};
+int dwtx_get_tiles(dwtx_ctx *ctx, int W, int H, dwtx_tiles *out);
+
+// Tiles straight from / to the pyramid (hilbert_dev.h): on the ring levels in the mask, tiles that are whole 32x32
+// squares need no linearised copy — the entropy stage reads (pack.hip) / writes (unpack.hip) them in the pyramid itself;
+// only the blocks the ring's edges cut (image border, LL quadrant) still go through `lin`.
 unsigned dwtx_square_levels(int W, int H);
 int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels);
 int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing, int levels_out, int W, int H,

@@ -7,10 +7,10 @@
 // holds the first five levels of the recursion for the 1024 points of a square (x | y << 8); what
 // the levels above do to a square's points is one swap and two XOR masks, uniform per square.
 //
-// For a ring level whose outer square is a full power of two n x n (n >= 64: widths[l+1] ==
-// heights[l+1] == lengths[l+1]), ring index r of encode.c:46-56 is curve index n*n/4 + r with no point
-// skipped, so the entropy stage's tile j (ring indices 1024j .. 1024j+1023) IS the 32x32 square with
-// curve block index n*n/4096 + j.
+// The entropy stage's tiles are the curve's blocks (dwtx_tiles, dwtx_internal.h): a block that lies wholly inside a
+// level's ring holds 1024 consecutive ring coefficients of encode.c:46-56, in curve order — it IS a tile, and it is
+// read from / written to the pyramid as the 32x32 square it is (blocks cut by the image border or the LL quadrant
+// go through the linearised copy).
 #pragma once
 
 #include "dwtx_internal.h"
@@ -138,12 +138,12 @@ __device__ __forceinline__ void square_positions16(const SquareMap &m, int lane,
 	}
 }
 
-// Tile j of a full-square ring level (outer side n) of one plane: the wave reads the 32x32 square as whole
+// Curve block `blk` of a ring level (outer side n) of one plane, a whole square: the wave reads it as whole
 // 128-byte rows, stages it in LDS (SQ_WORDS words, 16-byte aligned) and every lane picks up its 16 consecutive curve points.
-__device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr, int ppitch, int n, int j, int lane,
+__device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr, int ppitch, int n, int blk, int lane,
 	unsigned *lds, int (&val)[16])
 {
-	const SquareMap m = square_map(n, (unsigned)(((unsigned long)n * (unsigned long)n) >> 12) + (unsigned)j);
+	const SquareMap m = square_map(n, (unsigned)blk);
 	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
 #pragma unroll
 	for (int it = 0; it < 4; ++it) {
@@ -162,10 +162,10 @@ __device__ __forceinline__ void load_square16(const int *__restrict__ plane_pyr,
 }
 
 // the inverse: 16 consecutive curve points per lane -> the pyramid's 32x32 square
-__device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int ppitch, int n, int j, int lane, unsigned *lds,
+__device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int ppitch, int n, int blk, int lane, unsigned *lds,
 	const int (&val)[16])
 {
-	const SquareMap m = square_map(n, (unsigned)(((unsigned long)n * (unsigned long)n) >> 12) + (unsigned)j);
+	const SquareMap m = square_map(n, (unsigned)blk);
 	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
 	unsigned pos[16];
 	square_positions16(m, lane, pos);

@@ -138,13 +138,11 @@ constexpr int PTS = 4;   // curve points per thread (1024 / THREADS)
 template <bool INVERSE>
 __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__restrict__ blockbase,
 	int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch,
-	const int *__restrict__ missing, int C, int nplanes, unsigned skip_levels)
+	const int *__restrict__ missing, int C, int nplanes, unsigned skip_levels, const int *__restrict__ block_list)
 {
 	__shared__ int wcount[THREADS / 64];
-	const int b = blockIdx.x;
+	const int b = block_list ? block_list[blockIdx.x] : (int)blockIdx.x;
 	const int l = level_of_block(g, b);
-	if ((skip_levels >> l) & 1u)
-		return;   // the entropy stage reads / writes this level's tiles in the pyramid itself
 	const int lb = b - g.blk_first[l];
 	const int n = g.lengths[l + 1];
 	const int pl2 = g.blk_pts_log2[l];
@@ -153,6 +151,8 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 	if (total == 0)
 		return;
 	const bool full = total == npts;
+	if (((skip_levels >> l) & 1u) && full)
+		return;   // on these levels the entropy stage reads / writes whole squares in the pyramid itself
 	const int w0 = g.widths[l], h0 = g.heights[l], w1 = g.widths[l + 1], h1 = g.heights[l + 1];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const SquareMap smap = square_map(n, (unsigned)lb);   // uniform
@@ -289,6 +289,11 @@ struct dwtx_linplan {
 	LinGeom g;
 	int nblocks;
 	int *d_blockbase;
+	dwtx_tiles tiles;     // the non-empty blocks as the entropy stage's tiles (device arrays in one allocation at tiles.base)
+	// the blocks that are copied when the entropy stage takes the whole squares of every level it can (dwtx_square_levels):
+	// blocks the ring's edges cut, and the small levels — global block ids, ascending; copy_upto[l] = how many lie below level l
+	int *d_copy_list;
+	int copy_upto[DWTX_MAX_LEVELS + 1];
 	dwtx_linplan *next;
 };
 
@@ -335,9 +340,113 @@ static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
 		free(p);
 		return DWTX_ERR_DEVICE;
 	}
+	// the tile table: every non-empty block, level by level (built on the host once per geometry)
+	{
+		int *hb = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
+		if (!hb || hipMemcpyAsync(hb, p->d_blockbase, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+			hipStreamSynchronize(ctx->stream) != hipSuccess) {
+			free(hb);
+			(void)hipFree(p->d_blockbase);
+			free(p);
+			dwtx_set_error("plan download failed");
+			return DWTX_ERR_DEVICE;
+		}
+		int nt = 0;
+		for (int pass = 0; pass < 2; ++pass) {
+			int *tb = nullptr, *tk = nullptr;
+			unsigned short *tc = nullptr;
+			char *host = nullptr;
+			size_t o_cnt = 0, o_blk = 0, bytes = 0;
+			if (pass) {
+				o_blk = sizeof(int) * (size_t)nt;
+				o_cnt = 2 * sizeof(int) * (size_t)nt;
+				bytes = o_cnt + sizeof(unsigned short) * (size_t)nt + 64;
+				host = (char *)malloc(bytes);
+				if (!host) {
+					free(hb);
+					return DWTX_ERR_NOMEM;
+				}
+				tb = (int *)host;
+				tk = (int *)(host + o_blk);
+				tc = (unsigned short *)(host + o_cnt);
+			}
+			int t = 0;
+			for (int l = 0; l < g.levels; ++l) {
+				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
+				if (pass)
+					p->tiles.tile_first[l] = t;
+				for (int bb = first; bb < last; ++bb) {
+					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
+					if (c <= 0)
+						continue;
+					if (pass) {
+						tb[t] = hb[bb];
+						tk[t] = bb - first;
+						tc[t] = (unsigned short)c;
+					}
+					++t;
+				}
+			}
+			if (!pass) {
+				nt = t;
+				continue;
+			}
+			p->tiles.tile_first[g.levels] = t;
+			p->tiles.NT = t;
+			char *dev = nullptr;
+			if (hipMalloc((void **)&dev, bytes) != hipSuccess || hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+				free(host);
+				free(hb);
+				dwtx_set_error("tile table upload failed");
+				return DWTX_ERR_NOMEM;
+			}
+			p->tiles.base = (const int *)dev;
+			p->tiles.blk = (const int *)(dev + o_blk);
+			p->tiles.cnt = (const unsigned short *)(dev + o_cnt);
+			free(host);
+		}
+		{
+			const unsigned sq = dwtx_square_levels(W, H);
+			int *list = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
+			if (!list) {
+				free(hb);
+				return DWTX_ERR_NOMEM;
+			}
+			int m = 0;
+			for (int l = 0; l < g.levels; ++l) {
+				p->copy_upto[l] = m;
+				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
+				for (int bb = first; bb < last; ++bb) {
+					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
+					if (c > 0 && !(((sq >> l) & 1u) && c == (1 << g.blk_pts_log2[l])))
+						list[m++] = bb;
+				}
+			}
+			p->copy_upto[g.levels] = m;
+			if (hipMalloc((void **)&p->d_copy_list, sizeof(int) * (size_t)(m > 0 ? m : 1)) != hipSuccess ||
+				hipMemcpy(p->d_copy_list, list, sizeof(int) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) {
+				free(list);
+				free(hb);
+				dwtx_set_error("copy list upload failed");
+				return DWTX_ERR_NOMEM;
+			}
+			free(list);
+		}
+		free(hb);
+	}
 	p->next = ctx->plans;
 	ctx->plans = p;
 	*out = p;
+	return DWTX_OK;
+}
+
+int dwtx_get_tiles(dwtx_ctx *ctx, int W, int H, dwtx_tiles *out)
+{
+	dwtx_linplan *p;
+	const int rc = get_plan(ctx, W, H, &p);
+	if (rc)
+		return rc;
+	*out = p->tiles;
 	return DWTX_OK;
 }
 
@@ -347,6 +456,8 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 	while (p) {
 		dwtx_linplan *n = p->next;
 		(void)hipFree(p->d_blockbase);
+		(void)hipFree(const_cast<int *>(p->tiles.base));
+		(void)hipFree(p->d_copy_list);
 		free(p);
 		p = n;
 	}
@@ -357,23 +468,23 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 static int blocks_needed(const LinGeom &g, int levels, unsigned skip_levels)
 {
 	int nb = 0;
-	for (int l = 0; l < levels && l < g.levels; ++l)
-		if (!((skip_levels >> l) & 1u))
+	for (int l = 0; l < levels && l < g.levels; ++l)   // (a level of whole squares only — a power-of-two square image — has nothing to copy)
+		if (!((skip_levels >> l) & 1u) || g.widths[l + 1] != g.lengths[l + 1] || g.heights[l + 1] != g.lengths[l + 1])
 			nb = g.blk_first[l + 1];
 	return nb;
 }
 
+// levels that can hold whole 32x32 squares of ring coefficients (rows of a square are read / written as 16-byte pieces:
+// the row pitch must keep them aligned)
 unsigned dwtx_square_levels(int W, int H)
 {
 	dwtx_geom g;
 	if (dwtx_geometry(&g, W, H) || (W & 3))
 		return 0u;
 	unsigned mask = 0;
-	for (int l = 0; l < g.levels; ++l) {
-		const int n = g.lengths[l + 1];
-		if (n >= 64 && g.widths[l + 1] == n && g.heights[l + 1] == n)
+	for (int l = 0; l < g.levels; ++l)
+		if (g.lengths[l + 1] >= 64)
 			mask |= 1u << l;
-	}
 	return mask;
 }
 
@@ -398,10 +509,13 @@ int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W
 	const long ps = (long)W * H;
 	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
 		g.widths[0], g.heights[0], lin, ps, const_cast<int *>(pyr), ps, W);
-	const int nb = blocks_needed(g, g.levels, skip_levels);   // (a grid over the skipped levels' blocks would only start and end)
+	// (a grid over blocks that are not copied would only start and end: the usual skip mask has its list of blocks)
+	const bool listed = skip_levels && skip_levels == dwtx_square_levels(W, H);
+	const int nb = listed ? p->copy_upto[g.levels] : blocks_needed(g, g.levels, skip_levels);
 	if (nb)
 		hipLaunchKernelGGL(k_ring_copy<false>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
-			g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels);
+			g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels,
+			listed ? (const int *)p->d_copy_list : (const int *)nullptr);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
@@ -437,10 +551,12 @@ int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, cons
 		g.widths[0], g.heights[0], const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow);
 	if (levels_out > 0) {
 		g.levels = levels_out;   // only rings 0..levels_out-1 are rebuilt
-		const int nb = blocks_needed(g, levels_out, skip_levels);
+		const bool listed = skip_levels && skip_levels == dwtx_square_levels(W, H);
+		const int nb = listed ? p->copy_upto[levels_out] : blocks_needed(g, levels_out, skip_levels);
 		if (nb)
 			hipLaunchKernelGGL(k_ring_copy<true>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
-				ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels);
+				ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels,
+				listed ? (const int *)p->d_copy_list : (const int *)nullptr);
 	}
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;

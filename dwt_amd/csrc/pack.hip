@@ -71,6 +71,10 @@ struct PackGeom {
 	int side[DWTX_MAX_LEVELS + 1];          // outer side of ring level l (lengths[l+1])
 	int pixels[DWTX_MAX_LEVELS + 1];
 	int tile_first[DWTX_MAX_LEVELS + 1];   // tile_first[levels] = tiles per plane
+	// the tiles (dwtx_tiles): ring index of a tile's first coefficient, its coefficients, its block on the level's curve
+	const int *tile_base;
+	const unsigned short *tile_cnt;
+	const int *tile_blk;
 };
 
 struct ImgInfo {
@@ -189,21 +193,22 @@ struct __attribute__((packed, aligned(4))) Int4U {
 	int x, y, z, w;
 };
 
-__device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__restrict__ lin, int plane, int l, int j, int lane, int nvalid,
+__device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__restrict__ lin, int plane, int l, int tile, int lane, int nvalid,
 	int nv, unsigned *lds, int (&val)[16])
 {
-	if ((g.sq_levels >> l) & 1u) {   // uniform
-		load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], j, lane, lds, val);
+	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {   // uniform
+		load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
 		return;
 	}
-	const int *src = lin + (long)plane * g.total + g.pixels[l] + (long)j * TILE + 16 * lane;
+	const int tbase = g.tile_base[tile];
+	const int *src = lin + (long)plane * g.total + g.pixels[l] + tbase + 16 * lane;
 	// A ring starts wherever the levels before it end: its tiles are 16-byte aligned only by luck (always for
 	// power-of-two shapes).  A 16-byte load from a 4-byte aligned address is split up by the memory pipeline, so
 	// an unaligned tile is read as five aligned quads around the lane's 16 coefficients and shifted in registers
 	// by the ring's (uniform) misalignment.  The quad after a ring's last tile may lie outside the buffer: that
 	// tile takes the scalar path.
 	const int k = (int)(((uintptr_t)src >> 2) & 3);   // uniform: lanes are 64 bytes apart
-	const bool last_of_ring = g.pixels[l] + (long)(j + 1) * TILE >= g.pixels[l + 1];
+	const bool last_of_ring = g.pixels[l] + (long)tbase + TILE >= g.pixels[l + 1];
 	if (nvalid == TILE && (k == 0 || !last_of_ring)) {
 		const int4 *A = reinterpret_cast<const int4 *>(src - k);
 		int t[20];
@@ -264,15 +269,13 @@ __device__ __forceinline__ void hist_load(const PackGeom &g, const int *__restri
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
-	const long ring1 = g.pixels[l + 1];
-	const long base = g.pixels[l] + (long)(tile - g.tile_first[l]) * TILE;
-	nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const long base = g.pixels[l] + g.tile_base[tile];
+	nvalid = g.tile_cnt[tile];
 	ok = 0xffffu;
-	if ((g.sq_levels >> l) & 1u) {
+	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {
 		// the tile is a 32x32 square of the pyramid (hilbert_dev.h); a histogram does not care about the order:
 		// every lane takes four consecutive coefficients of four rows
-		const SquareMap m = square_map(g.side[l], (unsigned)(((unsigned long)g.side[l] * (unsigned long)g.side[l]) >> 12) +
-			(unsigned)(tile - g.tile_first[l]));
+		const SquareMap m = square_map(g.side[l], (unsigned)g.tile_blk[tile]);
 		const int *sq = g.pyr + (long)plane * g.total + (long)(m.my & ~31u) * g.W + (m.mx & ~31u);
 #pragma unroll
 		for (int it = 0; it < 4; ++it) {
@@ -660,9 +663,7 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_count(PackGeom g, Work w)
 		seg_unpack(sd[k], c, l, p);
 		const int j = e - eb[k];
 		const int ntile = g.tile_first[l + 1] - g.tile_first[l];
-		const long ring = (long)g.pixels[l + 1] - g.pixels[l];
-		const long left = ring - (long)j * TILE;
-		const int cnt = left < TILE ? (int)left : TILE;
+		const int cnt = g.tile_cnt[g.tile_first[l] + j];
 		const unsigned short *cum = w.cum + ((long)(img * g.C + c) * w.NT + g.tile_first[l] + j) * NCUM;
 		const int z = cum[p], upto = cum[p + 1];
 		w.ent_seg[img * w.ES + e] = (unsigned short)k;
@@ -1177,9 +1178,7 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
 	const int j = tile - g.tile_first[l];
-	const long ring1 = g.pixels[l + 1];
-	const long base = g.pixels[l] + (long)j * TILE;
-	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const int nvalid = g.tile_cnt[tile];
 	const int P = I.planes[c] < MAX_PLANES ? I.planes[c] : MAX_PLANES;
 	const unsigned live = w.live[(long)img * 48 + c * 16 + l];   // planes of this ring that are coded (k_cut)
 	if (!live)
@@ -1202,7 +1201,7 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	// ---- the coefficients, once (the class table's LDS words stage a pyramid square meanwhile) ----
 	static_assert(sizeof(L.tab) >= sizeof(unsigned) * SQ_WORDS, "the class table doubles as the square's staging area");
 	int val[16];
-	load_tile16(g, lin, plane, l, j, lane, nvalid, nv, L.tab, val);
+	load_tile16(g, lin, plane, l, tile, lane, nvalid, nv, L.tab, val);
 	// per-plane bookkeeping of this tile's entries (lanes 0..15 take a plane each): three dependent look-ups
 	// whose results are only needed after the first passes over the coefficients — they stay in registers till then
 	unsigned my_tokbase = 0;
@@ -2235,12 +2234,18 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	g.W = W;
 	g.H = H;
 	g.total = (long)W * H;
-	int NT = 0;
-	for (int l = 0; l < g.levels; ++l) {
-		g.tile_first[l] = NT;
-		NT += (int)(((long)g.pixels[l + 1] - g.pixels[l] + TILE - 1) / TILE);
+	dwtx_tiles tiles;
+	{
+		const int rc = dwtx_get_tiles(ctx, W, H, &tiles);
+		if (rc)
+			return rc;
 	}
-	g.tile_first[g.levels] = NT;
+	const int NT = tiles.NT;
+	for (int l = 0; l <= g.levels; ++l)
+		g.tile_first[l] = tiles.tile_first[l];
+	g.tile_base = tiles.base;
+	g.tile_cnt = tiles.cnt;
+	g.tile_blk = tiles.blk;
 
 	Work w;
 	memset(&w, 0, sizeof(w));

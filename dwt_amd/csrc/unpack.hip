@@ -71,6 +71,10 @@ struct UnpackGeom {
 	int *pyr;                                 // pyramid planes (pitch W) that take the tiles of the levels in sq_levels, or null
 	unsigned sq_levels;                       // ring levels written as 32x32 squares of the pyramid instead of into `lin` (hilbert_dev.h)
 	int side[DWTX_MAX_LEVELS + 1];            // outer side of ring level l (lengths[l+1])
+	// the tiles (dwtx_tiles): ring index of a tile's first coefficient, its coefficients, its block on the level's curve
+	const int *tile_base;
+	const unsigned short *tile_cnt;
+	const int *tile_blk;
 };
 
 struct DecInfo {
@@ -1839,10 +1843,9 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
-	const int j = tile - g.tile_first[l];
-	const long ring1 = g.pixels[l + 1];
-	const long base = g.pixels[l] + (long)j * TILE;
-	const int nvalid = (int)(ring1 - base < TILE ? ring1 - base : TILE);
+	const unsigned tbase = (unsigned)g.tile_base[tile];   // ring index of the tile's first coefficient
+	const long base = g.pixels[l] + (long)tbase;
+	const int nvalid = g.tile_cnt[tile];
 	const int first = 16 * lane;
 	const int nv = nvalid - first < 0 ? 0 : nvalid - first > 16 ? 16 : nvalid - first;   // this lane's coefficients
 	const int vb = first < nvalid ? first : nvalid;                                      // coefficients in the lanes before
@@ -1913,7 +1916,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			sv0[q] = sp[lane];
 			if (lane < SYMW - 64)
 				sv1[q] = sp[64 + lane];
-			const unsigned r2t = (unsigned)j * TILE - rank;                        // refinement index of the tile's first significant coefficient
+			const unsigned r2t = tbase - rank;                                     // refinement index of the tile's first significant coefficient
 			const unsigned long long rbit = b2 + r2t;
 			const long rw = (long)(rbit >> 5) + lane;
 			if (lane < REFW && r2t < n2 && rw < stream_words)
@@ -1950,7 +1953,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 			unsigned s32 = __builtin_amdgcn_alignbit(sw[1], sw[0], (srel & 15u) * 2u);
 			// refinement bits that the stream still holds for this lane (a truncated stream ends inside some block)
 			const unsigned sb4 = (unsigned)vb - nb;                          // significant coefficients in the lanes before
-			const unsigned r2 = (unsigned)j * TILE - rank + sb4;             // refinement index of this lane's first significant one
+			const unsigned r2 = tbase - rank + sb4;                          // refinement index of this lane's first significant one
 			const unsigned cs = (unsigned)nv - ci;
 			const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
 			const unsigned rrel = ap_refbit[wv][p] + sb4;
@@ -1978,8 +1981,8 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 		}
 		sq_wave_sync();   // the next batch overwrites the slices
 	}
-	if ((g.sq_levels >> l) & 1u) {
-		// this level's tile is a 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
+	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {
+		// the tile is a whole 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
 		// with the dead-zone bias of planes that were never decoded (decode.c:51-58)
 		const int m = I.missing[c * 16 + l] - 2;
 		const int bias = m >= 0 ? 1 << m : 0;
@@ -1991,7 +1994,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 				v += v < 0 ? -bias : bias;
 			val[i] = v;
 		}
-		store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], j, lane, ap_mem[threadIdx.x >> 6], val);
+		store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], g.tile_blk[tile], lane, ap_mem[threadIdx.x >> 6], val);
 		return;
 	}
 	int *dst = lin + (long)plane * g.lin_stride + base + first;
@@ -2023,8 +2026,7 @@ __global__ __launch_bounds__(256) void k_tiles_init(UnpackGeom g, DWork w, int n
 	int l = 0;
 	while (l + 1 < g.levels && tile >= g.tile_first[l + 1])
 		++l;
-	const long left = (long)g.pixels[l + 1] - g.pixels[l] - (long)(tile - g.tile_first[l]) * TILE;
-	w.tile_nonsig[(long)plane * w.NT + tile] = (unsigned short)(left < TILE ? left : TILE);
+	w.tile_nonsig[(long)plane * w.NT + tile] = g.tile_cnt[tile];
 }
 
 // The chunk tables are laid out for the stream stride, but only the chunks that hold stream bytes are
@@ -2086,12 +2088,18 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	unsigned part_mask[MAX_PARTS] = { 0u, 0u, 0u, 0u };
 	int part_first[MAX_PARTS + 1] = { 0, 0, 0, 0, 0 };   // images [part_first[k], part_first[k+1]) are part k
 	auto part_of = [&](int i0) { int k = 0; while (k + 1 < MAX_PARTS && part_first[k + 1] <= i0 && part_first[k + 1] > 0) ++k; return k; };
-	int NT = 0;
-	for (int l = 0; l < g.levels; ++l) {
-		g.tile_first[l] = NT;
-		NT += (int)(((long)g.pixels[l + 1] - g.pixels[l] + TILE - 1) / TILE);
+	dwtx_tiles tiles;
+	{
+		const int rc_tiles = dwtx_get_tiles(ctx, W, H, &tiles);
+		if (rc_tiles)
+			return rc_tiles;
 	}
-	g.tile_first[g.levels] = NT;
+	const int NT = tiles.NT;
+	for (int l = 0; l <= g.levels; ++l)
+		g.tile_first[l] = tiles.tile_first[l];
+	g.tile_base = tiles.base;
+	g.tile_cnt = tiles.cnt;
+	g.tile_blk = tiles.blk;
 	const int nplanes = n * C;
 
 	DWork w;
