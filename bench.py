@@ -106,6 +106,14 @@ class Runner:
         self.rank, self.world, self.dev = rank, world, dev
         self.pix = ctx.synth_pixels(B, H, W, C, seed0=rank * B, kind=0)      # resident in HBM before the timed region
         self.stride = ctx.lib.dwtx_encode_bound(W, H, C)
+        if B * self.stride > (8 << 30):
+            # The worst-case bound (3 bytes per sample) times a thousand frames is tens of gigabytes of output rows, and the
+            # decoder's chunk tables are laid out per stride: rows sized from the streams of a few probe frames, half as
+            # much again (a stream that did not fit would be clipped like a CAPACITY and fail the lossless check below)
+            probe, pinfo = ctx.encode_device(self.pix[:8])
+            self.stride = (int(ctx.stream_lengths(pinfo).max().item()) * 3 // 2 + 64 + 7) // 8 * 8
+            del probe, pinfo
+            torch.cuda.empty_cache()
         slots = 2 if world > 1 else 1
         self.out = [torch.empty((B, self.stride), dtype=torch.uint8, device=dev) for _ in range(slots)]
         self.info = [torch.empty((B, ctypes.sizeof(dwt_amd.StreamInfo)), dtype=torch.uint8, device=dev) for _ in range(slots)]
@@ -523,10 +531,13 @@ def main():
                 "lossless_with_index": same}
 
     if world == 1 and args.extras:
-        # BASELINE.json configs[1] literally (one frame), configs[2] and configs[4] geometry (short runs)
+        # BASELINE.json configs[1] literally (one frame), configs[2], configs[3] and configs[4] geometry (short runs);
+        # each on a context of its own, the main workload's scratch given back first (configs[2] needs most of the HBM)
         extras = {}
-        del run
+        del run, d, dinfos
+        ctx.close()
         torch.cuda.empty_cache()
+        ctx = dwt_amd.Context(local)
         one = Runner(ctx, torch, dwt_amd, "gray4096", 1, 0, 1, dev)
         t1, (s1, l1, d1, i1), _ = one.timed(5, 2, fence)
         em, _ = timed(lambda: ctx.encode_device(one.pix, out=one.out[0], info=one.info[0]))
@@ -540,24 +551,32 @@ def main():
         }
         result["single_frame"]["sidecar_index"] = with_index(ctx, one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, 1, one.dec, one.pix)
         del one, s1, d1
+        ctx.close()
+        torch.cuda.empty_cache()
         for name in ("rgb1080p", "rgb4096"):
             if name == args.workload:
                 continue
             torch.cuda.empty_cache()
             # a context of its own: scratch sized and placed for this workload, as when it is the main one (inside the
             # scratch the gray batch left behind, 16 frames of 4096x4096 RGB ran anywhere between 18.5 and 27 ms per step)
-            cx = dwt_amd.Context(local)
-            try:
-                r2 = Runner(cx, torch, dwt_amd, name, 0, 0, 1, dev)
-                r2.step()   # (sizes every scratch buffer)
-                torch.cuda.synchronize()
-            except (RuntimeError, MemoryError) as err:   # the configuration's full batch does not fit beside what else lives on this GPU: a quarter of it
-                r2 = None
-                torch.cuda.empty_cache()
-                cx.close()
+            def attempt(frames):
                 cx = dwt_amd.Context(local)
-                r2 = Runner(cx, torch, dwt_amd, name, max(1, WORKLOADS[name][3] // 4), 0, 1, dev)
-                CONFIG_OF[name] += f" at a quarter of its batch ({type(err).__name__} at the full one)"
+                try:
+                    r = Runner(cx, torch, dwt_amd, name, frames, 0, 1, dev)
+                    r.step()   # (sizes every scratch buffer)
+                    torch.cuda.synchronize()
+                    return cx, r, None
+                except (RuntimeError, MemoryError) as err:
+                    cx.close()
+                    return None, None, type(err).__name__
+
+            cx, r2, why = attempt(0)
+            if r2 is None:   # the configuration's full batch did not fit: half of it, and say so
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                cx, r2, why2 = attempt(max(1, WORKLOADS[name][3] // 2))
+                CONFIG_OF[name] += f" at half of its batch ({why} at the full one)"
             XS = 6   # steps of a side workload (2 warm-up steps: a 3-step run once caught a cold start and read 30 % low)
             t2, (s2, l2, d2, i2), _ = r2.timed(XS, 2, fence)
             ok2 = bool(torch.equal(d2.view(r2.B, r2.H, r2.W, r2.C), r2.pix)) and all(i.status == 0 and not i.truncated for i in i2)

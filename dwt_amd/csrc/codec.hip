@@ -29,13 +29,19 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 	if (!a || !b)
 		return DWTX_ERR_NOMEM;
 	int rc;
+	// the forward transform leaves the tiles' magnitude histograms behind where it can (encode.c:112-131's maximum and
+	// everything the entropy stage counts before it codes): the coefficients are not read a second time for them
+	dwtx_hist_sink sink;
+	unsigned hist_levels = 0;
+	if ((rc = dwtx_hist_begin(ctx, W, H, C, n, &sink)))
+		return rc;
 	if (dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C)) {
-		if ((rc = dwtx_fwd_pixels8(ctx, b, dev_pix, W, H, C, n)))              // encode.c:155-159 in one pass
+		if ((rc = dwtx_fwd_pixels8_hist(ctx, b, dev_pix, W, H, C, n, &sink, &hist_levels)))   // encode.c:155-159 in one pass
 			return rc;
 	} else {
 		if ((rc = dwtx_planes_from_pixels(ctx, a, dev_pix, W, H, C, n)))       // encode.c:155-156
 			return rc;
-		if ((rc = dwtx_transformation_fwd(ctx, b, a, W, H, n * C)))            // encode.c:159
+		if ((rc = dwtx_transformation_fwd_hist(ctx, b, a, W, H, n * C, &sink, &hist_levels)))   // encode.c:159
 			return rc;
 	}
 	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
@@ -44,7 +50,7 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 		return rc;
 	if (lifted)
 		DWTX_HIP(hipEventRecord(lifted, ctx->stream));
-	return dwtx_encode_planes_ex(ctx, a, b, sq, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
+	return dwtx_encode_planes_ex(ctx, a, b, sq, hist_levels, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
 }
 
 // pixels (device) -> streams (device); async on the context's stream.

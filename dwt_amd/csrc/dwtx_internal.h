@@ -125,7 +125,28 @@ struct dwtx_tiles {
 	const int *base;              // device, [NT]
 	const unsigned short *cnt;    // device, [NT]
 	const int *blk;               // device, [NT]
+	// block (bx, by) of level l's curve square (32x32 pyramid positions each, lengths[l+1] / 32 = nbs[l] blocks per side)
+	// -> its tile, -1 for a block without ring coefficients: xy2tile[xy_first[l] + by * nbs[l] + bx]; levels below 64 have none
+	const int *xy2tile;           // device
+	int xy_first[DWTX_MAX_LEVELS + 1];
+	int nbs[DWTX_MAX_LEVELS];
 };
+
+// Where the forward transform drops the tiles' magnitude histograms while it still holds the coefficients in registers
+// (lift.hip k_fwd_level_w; what k_hist would otherwise read them from memory again for).  cum32: [plane][NT][16] words,
+// word b of a tile = #(|v| < 2^(2b)) | #(|v| < 2^(2b+1)) << 16, zero before the transform adds to them; tile_mx:
+// [plane][NTP] OR of the tile's magnitudes.
+struct dwtx_hist_sink {
+	unsigned *cum32;
+	unsigned *tile_mx;
+	int NT, NTP;
+	dwtx_tiles tiles;
+};
+int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *sink);   // pack.hip
+// lift.hip: the forward transform with the histograms of the levels it can take (returned in *hist_levels, bit l = ring level l)
+int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels);
+int dwtx_transformation_fwd_hist(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes, const dwtx_hist_sink *sink,
+	unsigned *hist_levels);
 int dwtx_get_tiles(dwtx_ctx *ctx, int W, int H, dwtx_tiles *out);
 
 // Tiles straight from / to the pyramid (hilbert_dev.h): on the ring levels in the mask, tiles that are whole 32x32
@@ -135,7 +156,8 @@ unsigned dwtx_square_levels(int W, int H);
 int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels);
 int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing, int levels_out, int W, int H,
 	int C, int n, unsigned skip_levels);
-int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, int W, int H, int C, int n,
+// hist_levels: ring levels whose tile histograms the forward transform has already written (dwtx_hist_begin)
+int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C, int n,
 	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info);
 
 // unpack.hip: dwtx_decode_planes with a host callback per finished part of the batch (see there)

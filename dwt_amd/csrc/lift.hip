@@ -250,10 +250,90 @@ struct I2 {
 	int a, b;
 };
 
+// The tiles' magnitude histograms, dropped by the forward kernel while it holds the coefficients (dwtx_hist_sink):
+// the level's blocks of 32x32 pyramid positions are the entropy stage's tiles.
+struct HistArgs {
+	unsigned *cum32;       // [plane][NT][16]
+	unsigned *tile_mx;     // [plane][NTP]
+	const int *xy2tile;    // this level's [by * nbs + bx] -> tile
+	int NT, NTP, nbs;
+};
+
 struct LevelArgsW {
 	LevelArgs a;
 	int nquads;       // w / 4
+	HistArgs hist;
 };
+
+// Per lane and subband: counts of "magnitude below 2^q" for q = 0..15 — nibbles of R for the last few coefficients
+// (adding 0x1111.. << 4t per coefficient, t its bit count), folded into the bytes of ev (even q) and od (odd q) before a
+// nibble can overflow; mx = OR of the magnitudes.  The same counts k_hist (pack.hip) makes from memory.
+struct HistAcc {
+	unsigned long long R, ev, od;
+	unsigned mx;
+};
+
+__device__ __forceinline__ void hist_add(HistAcc &h, int v)
+{
+	const unsigned a = (unsigned)(v < 0 ? -v : v);
+	h.mx |= a;
+	// (a magnitude of 2^15 and more counts as 15 bits here: its plane has more than 16 bit planes — mx says so — and
+	// is refused before any of these counts is used)
+	const unsigned t = min(32u - (unsigned)__clz((int)a), 15u);
+	h.R += 0x1111111111111111ull << (4u * t);
+}
+
+__device__ __forceinline__ void hist_fold(HistAcc &h)
+{
+	h.ev += h.R & 0x0f0f0f0f0f0f0f0full;
+	h.od += (h.R >> 4) & 0x0f0f0f0f0f0f0f0full;
+	h.R = 0;
+}
+
+// sum over the 16 lanes of a DPP row (its last lane ends up with the total)
+__device__ __forceinline__ unsigned row16_add(unsigned v)
+{
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+	return v;
+}
+
+__device__ __forceinline__ unsigned row16_or(unsigned v)
+{
+	v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+	v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+	v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+	v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+	return v;
+}
+
+// The 16 lanes of a row hold one block's columns: their counts, summed, are added to the block's tile (blocks that
+// straddle two strips or two subbands get several such contributions).  All lanes of the wave take part.
+__device__ __forceinline__ void hist_flush(HistAcc &h, const HistArgs &H, int plane, int bx, int by, int lane)
+{
+	hist_fold(h);
+	unsigned D[8];
+#pragma unroll
+	for (int b = 0; b < 8; ++b)
+		D[b] = row16_add(((unsigned)(h.ev >> (8 * b)) & 0xffu) | ((unsigned)(h.od >> (8 * b)) & 0xffu) << 16);
+	const unsigned mx = row16_or(h.mx);
+	if ((lane & 15) == 15 && bx < H.nbs && by < H.nbs) {
+		const int tile = H.xy2tile[by * H.nbs + bx];
+		if (tile >= 0) {
+			unsigned *rec = H.cum32 + ((long)plane * H.NT + tile) * 16;
+#pragma unroll
+			for (int b = 0; b < 8; ++b)
+				if (D[b])
+					atomicAdd(rec + b, D[b]);
+			if (mx)
+				atomicOr(H.tile_mx + (long)plane * H.NTP + tile, mx);
+		}
+	}
+	h.ev = h.od = 0;
+	h.mx = 0;
+}
 
 struct FwdRaw {
 	int4 x;
@@ -289,19 +369,36 @@ __device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<int>, const int *__restrict_
 	return r;
 }
 
-__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<uint8_t>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int)
+// (8-bit rows wait for their turn as they were loaded — four pixels in a word, the neighbours' three in another — and
+// are widened when used: two registers per row in flight instead of seven)
+struct FwdRaw8 {
+	unsigned v;       // pixels 4q .. 4q+3
+	unsigned edge;    // x[4q+4] (lane 63) | x[4q-2] << 8 | x[4q-1] << 16 (lane 0)
+};
+
+__device__ __forceinline__ FwdRaw8 fwd_load_w(SrcTag<uint8_t>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int)
 {
-	FwdRaw r;
-	const unsigned v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
-	r.x = make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
-	r.xr = 0;
-	r.left = make_int2(0, 0);
+	FwdRaw8 r;
+	r.v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
+	r.edge = 0;
 	if (lane == 63 && valid && q + 1 < nquads)
-		r.xr = row[4 * q + 4];
+		r.edge = row[4 * q + 4];
 	if (lane == 0 && valid && q > 0)
-		r.left = make_int2(row[4 * q - 2], row[4 * q - 1]);
+		r.edge = (unsigned)row[4 * q - 2] << 8 | (unsigned)row[4 * q - 1] << 16;
 	return r;
 }
+
+__device__ __forceinline__ FwdRaw fwd_widen(const FwdRaw &r, int) { return r; }
+__device__ __forceinline__ FwdRaw fwd_widen(const FwdRaw8 &r, int)
+{
+	FwdRaw o;
+	o.x = make_int4((int)(r.v & 255u), (int)((r.v >> 8) & 255u), (int)((r.v >> 16) & 255u), (int)(r.v >> 24));
+	o.xr = (int)(r.edge & 255u);
+	o.left = make_int2((int)((r.edge >> 8) & 255u), (int)(r.edge >> 16));
+	return o;
+}
+
+
 
 // image.h:52-65: channel ch (0 Y, 1 Co, 2 Cg) of one RGB pixel
 __device__ __forceinline__ int ycocg_of(int r, int g, int b, int ch)
@@ -312,29 +409,60 @@ __device__ __forceinline__ int ycocg_of(int r, int g, int b, int ch)
 	return ch == 0 ? t + tdiv2(cg) : ch == 1 ? co : cg;
 }
 
-__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<Rgb8>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int ch)
+// (RGB rows wait packed as well: the four pixels' three words and two words of neighbours; the colour transform of
+// image.h:52-65 happens when the row is used)
+struct FwdRawRgb {
+	unsigned a, b, c;   // pixels 4q .. 4q+3
+	unsigned e0, e1;    // lane 63: e0 = the word with pixel 4q+4; lane 0: bytes 12q-8 .. 12q-1 (pixels 4q-2 and 4q-1 are the last six)
+};
+
+__device__ __forceinline__ FwdRawRgb fwd_load_w(SrcTag<Rgb8>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int ch)
 {
-	FwdRaw r;
+	FwdRawRgb r;
 	// four pixels = twelve bytes = three aligned words (the row pitch 3*w is a multiple of 4)
 	const unsigned *w = reinterpret_cast<const unsigned *>(row + 12 * q);
-	const unsigned a = valid ? w[0] : 0u, b = valid ? w[1] : 0u, c = valid ? w[2] : 0u;
-	r.x.x = ycocg_of((int)(a & 255u), (int)((a >> 8) & 255u), (int)((a >> 16) & 255u), ch);
-	r.x.y = ycocg_of((int)(a >> 24), (int)(b & 255u), (int)((b >> 8) & 255u), ch);
-	r.x.z = ycocg_of((int)((b >> 16) & 255u), (int)(b >> 24), (int)(c & 255u), ch);
-	r.x.w = ycocg_of((int)((c >> 8) & 255u), (int)((c >> 16) & 255u), (int)(c >> 24), ch);
-	r.xr = 0;
-	r.left = make_int2(0, 0);
-	if (lane == 63 && valid && q + 1 < nquads) {
-		const unsigned n = w[3];
-		r.xr = ycocg_of((int)(n & 255u), (int)((n >> 8) & 255u), (int)((n >> 16) & 255u), ch);
-	}
+	r.a = valid ? w[0] : 0u;
+	r.b = valid ? w[1] : 0u;
+	r.c = valid ? w[2] : 0u;
+	r.e0 = r.e1 = 0u;
+	if (lane == 63 && valid && q + 1 < nquads)
+		r.e0 = w[3];
 	if (lane == 0 && valid && q > 0) {
-		const unsigned m = *(w - 2), n = *(w - 1);   // bytes 12q-8 .. 12q-1: pixels 4q-2 and 4q-1 are the last six
-		r.left = make_int2(ycocg_of((int)((m >> 16) & 255u), (int)(m >> 24), (int)(n & 255u), ch),
-			ycocg_of((int)((n >> 8) & 255u), (int)((n >> 16) & 255u), (int)(n >> 24), ch));
+		r.e0 = *(w - 2);
+		r.e1 = *(w - 1);
 	}
 	return r;
 }
+
+__device__ __forceinline__ FwdRaw fwd_widen(const FwdRawRgb &r, int ch)
+{
+	FwdRaw o;
+	const unsigned a = r.a, b = r.b, c = r.c;
+	o.x.x = ycocg_of((int)(a & 255u), (int)((a >> 8) & 255u), (int)((a >> 16) & 255u), ch);
+	o.x.y = ycocg_of((int)(a >> 24), (int)(b & 255u), (int)((b >> 8) & 255u), ch);
+	o.x.z = ycocg_of((int)((b >> 16) & 255u), (int)(b >> 24), (int)(c & 255u), ch);
+	o.x.w = ycocg_of((int)((c >> 8) & 255u), (int)((c >> 16) & 255u), (int)(c >> 24), ch);
+	// (only lane 63 uses xr and only lane 0 uses left: whatever the other lanes make of their zero words is never read)
+	const unsigned n = r.e0;
+	o.xr = ycocg_of((int)(n & 255u), (int)((n >> 8) & 255u), (int)((n >> 16) & 255u), ch);
+	const unsigned m = r.e0, k = r.e1;
+	o.left = make_int2(ycocg_of((int)((m >> 16) & 255u), (int)(m >> 24), (int)(k & 255u), ch),
+		ycocg_of((int)((k >> 8) & 255u), (int)((k >> 16) & 255u), (int)(k >> 24), ch));
+	return o;
+}
+
+template <typename SrcT>
+struct RawOf {
+	typedef FwdRaw type;
+};
+template <>
+struct RawOf<uint8_t> {
+	typedef FwdRaw8 type;
+};
+template <>
+struct RawOf<Rgb8> {
+	typedef FwdRawRgb type;
+};
 
 __device__ __forceinline__ void fwd_lift_w(const FwdRaw &r, int q, int lane, int nquads, I2 &lo, I2 &hi)
 {
@@ -407,7 +535,7 @@ __device__ __forceinline__ void xcd_strip(int &bx, int &by)
 	}
 }
 
-template <typename SrcT>
+template <typename SrcT, bool HIST>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -428,21 +556,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 
 	int jj = j0 > 0 ? j0 - 1 : 0;
 	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
+	typedef typename RawOf<SrcT>::type Raw;
 	{
-		const FwdRaw r0 = fwd_load_w(SrcTag<SrcT>(), src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid, ch);
-		fwd_lift_w(r0, q, lane, A.nquads, l0, h0);
+		const Raw r0 = fwd_load_w(SrcTag<SrcT>(), src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid, ch);
+		fwd_lift_w(fwd_widen(r0, ch), q, lane, A.nquads, l0, h0);
 	}
 	// rows 2jj+1, 2jj+2 of the next two iterations are kept in flight: one wave alone cannot cover
 	// the HBM latency with a single row pair outstanding
 	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
-	FwdRaw n1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 1), q, lane, A.nquads, valid, ch);
-	FwdRaw n2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 2), q, lane, A.nquads, valid, ch);
-	FwdRaw m1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 3), q, lane, A.nquads, valid, ch);
-	FwdRaw m2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 4), q, lane, A.nquads, valid, ch);
+	Raw n1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 1), q, lane, A.nquads, valid, ch);
+	Raw n2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 2), q, lane, A.nquads, valid, ch);
+	Raw m1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 3), q, lane, A.nquads, valid, ch);
+	Raw m2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 4), q, lane, A.nquads, valid, ch);
+	HistAcc hHL = { 0, 0, 0, 0 }, hLH = { 0, 0, 0, 0 }, hHH = { 0, 0, 0, 0 };
 	for (; jj < j1; ++jj) {
 		const int r1 = 2 * jj + 1, r2 = r1 + 1;
 		const bool odd_in = r1 < a.h;
-		const FwdRaw c1 = n1, c2 = n2;
+		const Raw c1 = n1, c2 = n2;
 		n1 = m1;
 		n2 = m2;
 		if (jj + 2 < j1) {
@@ -451,9 +581,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 		}
 		I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
 		if (odd_in)
-			fwd_lift_w(c1, q, lane, A.nquads, l1, h1);
+			fwd_lift_w(fwd_widen(c1, ch), q, lane, A.nquads, l1, h1);
 		if (r2 < a.h)
-			fwd_lift_w(c2, q, lane, A.nquads, l2, h2v);
+			fwd_lift_w(fwd_widen(c2, ch), q, lane, A.nquads, l2, h2v);
 		const I2 dl = i2_pred(l1, l0, l2);
 		const I2 dh = i2_pred(h1, h0, h2v);
 		if (jj >= j0 && valid) {
@@ -467,6 +597,34 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 			if (odd_in) {
 				st2(det + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
 				st2(det + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+			}
+		}
+		if (HIST && jj >= j0) {
+			// the detail coefficients of this row pair, as they were stored (cdf53.h:9-34 output): HL row jj, LH and HH row h2 + jj
+			if (valid) {
+				const I2 sh = odd_in ? i2_upd(h0, jj ? ph : dh, dh) : h0;
+				hist_add(hHL, sh.a);
+				hist_add(hHL, sh.b);
+				if (odd_in) {
+					hist_add(hLH, dl.a);
+					hist_add(hLH, dl.b);
+					hist_add(hHH, dh.a);
+					hist_add(hHH, dh.b);
+				}
+			}
+			if ((jj & 3) == 3) {   // eight coefficients per subband since the last fold: a nibble holds fifteen
+				hist_fold(hHL);
+				hist_fold(hLH);
+				hist_fold(hHH);
+			}
+			// a block ends where its 32 rows end (or the strip does): the rows of HL are jj, those of LH / HH h2 + jj
+			const bool last = jj == j1 - 1;
+			const int bxl = (2 * q) >> 5, bxh = (a.w2 + 2 * q) >> 5;
+			if (last || ((jj + 1) & 31) == 0)
+				hist_flush(hHL, A.hist, plane, bxh, jj >> 5, lane);
+			if (last || ((a.h2 + jj + 1) & 31) == 0) {
+				hist_flush(hLH, A.hist, plane, bxl, (a.h2 + jj) >> 5, lane);
+				hist_flush(hHH, A.hist, plane, bxh, (a.h2 + jj) >> 5, lane);
 			}
 		}
 		pl = dl;
@@ -1030,8 +1188,11 @@ static int pick_rpw(int strips_x, int h2, int nplanes)
 
 // in8 != nullptr: the source is 8-bit pixels, gray (in8_channels 1: plane p = image p) or interleaved RGB
 // (in8_channels 3: plane p = channel p%3 of image p/3 after YCoCg-R); needs a finest level the wide kernel takes
-static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int in8_channels, int W, int H, int nplanes)
+static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int in8_channels, int W, int H, int nplanes,
+	const dwtx_hist_sink *sink = nullptr, unsigned *hist_levels = nullptr)
 {
+	if (hist_levels)
+		*hist_levels = 0u;
 	if (!ctx || !out || (!in && !in8) || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
 	DWTX_ENTER(ctx);
@@ -1049,6 +1210,14 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			return DWTX_ERR_NOMEM;
 	}
 	const long full_ps = (long)W * H;
+	// histograms ride along from the finest level down for as long as the levels allow it (the wide kernel, blocks
+	// that the 16-lane rows cover exactly): pack.hip's k_hist counts the tiles of the levels below
+	bool hist_on = sink != nullptr && hist_levels != nullptr;
+	{
+		dwtx_geom gg;
+		if (hist_on && (dwtx_geometry(&gg, W, H) || gg.levels != T))
+			hist_on = false;
+	}
 	int tail_from = T;   // first step that runs inside the LDS tail kernel
 	for (int t = 0; t < T; ++t)
 		if (ws[t] <= TAIL_MAX && hs[t] <= TAIL_MAX) {
@@ -1115,19 +1284,38 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
 		if (bytes_in && !wide)
 			return DWTX_ERR_ARG;   // callers check dwtx_gray8_ok() first
+		const int level = T - 1 - t;   // the ring level this step's detail bands are
+		// (the RGB kernel is bound by its own arithmetic — every plane's launch unpacks the pixels and does the colour
+		// transform — and pays for the histogram in full: 3.2 -> 4.7 ms per 256 frames of 1080p against the 1.4 ms k_hist takes)
+		const bool hist_here = hist_on && wide && a.w2 % 32 == 0 && sink->tiles.nbs[level] > 0;
 		if (wide) {
 			LevelArgsW A;
 			A.nquads = a.w / 4;
 			const int sx = dwtx_cdiv(A.nquads, 64);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
 			A.a = a;
+			A.hist = HistArgs{ nullptr, nullptr, nullptr, 0, 0, 0 };
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
-			if (bytes_in && in8_channels == 3)
-				hipLaunchKernelGGL(k_fwd_level_w<Rgb8>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			if (hist_here) {
+				A.hist.cum32 = sink->cum32;
+				A.hist.tile_mx = sink->tile_mx;
+				A.hist.xy2tile = sink->tiles.xy2tile + sink->tiles.xy_first[level];
+				A.hist.NT = sink->NT;
+				A.hist.NTP = sink->NTP;
+				A.hist.nbs = sink->tiles.nbs[level];
+				*hist_levels |= 1u << level;
+				if (bytes_in && in8_channels == 3)
+					hipLaunchKernelGGL((k_fwd_level_w<Rgb8, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				else if (bytes_in)
+					hipLaunchKernelGGL((k_fwd_level_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				else
+					hipLaunchKernelGGL((k_fwd_level_w<int, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			} else if (bytes_in && in8_channels == 3)
+				hipLaunchKernelGGL((k_fwd_level_w<Rgb8, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_in)
-				hipLaunchKernelGGL(k_fwd_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_level_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
-				hipLaunchKernelGGL(k_fwd_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_level_w<int, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, 64);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
@@ -1154,6 +1342,21 @@ extern "C" int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *out, const int32_
 bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride)
 {
 	return W % 4 == 0 && (W > TAIL_MAX || H > TAIL_MAX) && image_stride % 4 == 0 && aligned_to(pix, 4);
+}
+
+int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels)
+{
+	if (!pix || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, (size_t)W * H * C))
+		return DWTX_ERR_ARG;
+	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C, sink, hist_levels);
+}
+
+int dwtx_transformation_fwd_hist(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes, const dwtx_hist_sink *sink,
+	unsigned *hist_levels)
+{
+	if (!in)
+		return DWTX_ERR_ARG;
+	return lift_fwd(ctx, out, in, nullptr, 0, W, H, nplanes, sink, hist_levels);
 }
 
 int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n)

@@ -406,6 +406,58 @@ static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
 			free(host);
 		}
 		{
+			// block coordinates -> tile (for the forward transform's histograms): hilbert.h:15-34 at block granularity
+			int total = 0;
+			for (int l = 0; l < g.levels; ++l) {
+				p->tiles.xy_first[l] = total;
+				p->tiles.nbs[l] = g.lengths[l + 1] >= 64 ? g.lengths[l + 1] >> BLK_LOG2 : 0;
+				total += p->tiles.nbs[l] * p->tiles.nbs[l];
+			}
+			p->tiles.xy_first[g.levels] = total;
+			int *tab = (int *)malloc(sizeof(int) * (size_t)(total > 0 ? total : 1));
+			if (!tab) {
+				free(hb);
+				return DWTX_ERR_NOMEM;
+			}
+			for (int l = 0; l < g.levels; ++l) {
+				const int nbs = p->tiles.nbs[l];
+				if (!nbs)
+					continue;
+				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
+				int t = p->tiles.tile_first[l];
+				for (int bb = first; bb < last; ++bb) {
+					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
+					unsigned x = 0, y = 0, d = (unsigned)(bb - first);   // the block's place on the nbs x nbs grid
+					for (unsigned sd = 1; sd < (unsigned)nbs; sd <<= 1) {
+						const unsigned rx = (d >> 1) & 1u, ry = (d ^ rx) & 1u;
+						if (rx && !ry) {
+							x ^= sd - 1;
+							y ^= sd - 1;
+						}
+						if (!ry) {
+							const unsigned tmp = x;
+							x = y;
+							y = tmp;
+						}
+						x |= rx ? sd : 0u;
+						y |= ry ? sd : 0u;
+						d >>= 2;
+					}
+					tab[p->tiles.xy_first[l] + (int)y * nbs + (int)x] = c > 0 ? t++ : -1;
+				}
+			}
+			int *dtab = nullptr;
+			if (hipMalloc((void **)&dtab, sizeof(int) * (size_t)(total > 0 ? total : 1)) != hipSuccess ||
+				hipMemcpy(dtab, tab, sizeof(int) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess) {
+				free(tab);
+				free(hb);
+				dwtx_set_error("block table upload failed");
+				return DWTX_ERR_NOMEM;
+			}
+			p->tiles.xy2tile = dtab;
+			free(tab);
+		}
+		{
 			const unsigned sq = dwtx_square_levels(W, H);
 			int *list = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
 			if (!list) {
@@ -458,6 +510,7 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 		(void)hipFree(p->d_blockbase);
 		(void)hipFree(const_cast<int *>(p->tiles.base));
 		(void)hipFree(p->d_copy_list);
+		(void)hipFree(const_cast<int *>(p->tiles.xy2tile));
 		free(p);
 		p = n;
 	}

@@ -102,7 +102,8 @@ struct RunMap {
 struct Work {
 	// per plane
 	unsigned short *cum;        // [nplanes][NT][32]
-	unsigned char *tile_top;    // [nplanes][NTP] every tile's own bit-plane count, 1 + ilog2(max |v|) (k_hist -> k_plan, k_code); NTP = NT rounded up to 16
+	unsigned *tile_mx;          // [nplanes][NTP] OR of the tile's magnitudes: its own bit-plane count is 1 + ilog2 of it (k_hist or the forward
+	                            // transform -> k_plan, k_code); NTP = NT rounded up to 4
 	// per image
 	ImgInfo *info;              // [n]
 	int *seg_desc;              // [n][MAX_SEGS]   c | l<<4 | (p+1)<<8
@@ -364,29 +365,66 @@ __device__ __forceinline__ void hist_finish(const Work &w, int plane, int tile, 
 		// cannot hold a device-coherent word, and that cost 0.7 ms per 400 000 tiles.)
 		cum[lane] = (unsigned short)(lane == NCUM - 1 ? (mx ? ilog2u(mx) + 1 : 0) : nvalid);
 	}
-	if (lane == 0)   // the same count once more in a dense array: k_plan reduces it, k_code asks it before loading the tile
-		w.tile_top[(long)plane * w.NTP + tile] = (unsigned char)(mx ? (ilog2u(mx) + 1 < 255 ? ilog2u(mx) + 1 : 255) : 0);
+	if (lane == 0)   // the magnitudes' OR once more in a dense array: k_plan reduces it, k_code asks it before loading the tile
+		w.tile_mx[(long)plane * w.NTP + tile] = mx;
 }
 
 // Two tiles per wave: both tiles' loads are in flight before the first is counted (the kernel only waits for memory).
 constexpr int HIST_TPW = 2;
 
-__global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w)
+// What the forward transform adds its histograms to (dwtx_hist_begin): a tile's record with the counts at zero, the
+// fields past the last plane at the tile's size, and no magnitude seen yet.
+__global__ __launch_bounds__(256) void k_hist_init(PackGeom g, Work w)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;   // dword i of the plane's records
+	const int plane = blockIdx.y;
+	if (i >= w.NT * (NCUM / 2))
+		return;
+	const int tile = i / (NCUM / 2), d = i - tile * (NCUM / 2);
+	const unsigned cnt = g.tile_cnt[tile];
+	reinterpret_cast<unsigned *>(w.cum + ((long)plane * w.NT + tile) * NCUM)[d] = d < 8 ? 0u : d < 15 ? cnt * 0x00010001u : cnt;
+	if (d == 0)
+		w.tile_mx[(long)plane * w.NTP + tile] = 0u;
+}
+
+// done_levels: ring levels whose tiles got their histograms from the forward transform (lift.hip): skipped here
+__global__ __launch_bounds__(256) void k_hist(PackGeom g, const int *__restrict__ lin, Work w, unsigned done_levels)
 {
 	const int lane = threadIdx.x & 63;
 	const int tile0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * HIST_TPW;
 	const int plane = blockIdx.y;
 	if (tile0 >= w.NT)
 		return;
+	if (done_levels) {   // (a wave's two tiles lie on one level, or the first is the last of its level: the pair is split then)
+		int l = 0;
+		while (l + 1 < g.levels && tile0 >= g.tile_first[l + 1])
+			++l;
+		const bool d0 = (done_levels >> l) & 1u;
+		const bool same = tile0 + 1 < g.tile_first[l + 1];
+		const bool d1 = same ? d0 : (l + 1 < g.levels ? ((done_levels >> (l + 1)) & 1u) != 0 : true);
+		if (d0 && d1)
+			return;
+		if (d0 != d1) {   // one tile of the pair: counted alone
+			const int t = d0 ? tile0 + 1 : tile0;
+			if (t < w.NT) {
+				int val1[16], nv1;
+				unsigned ok1;
+				hist_load(g, lin, plane, t, lane, val1, ok1, nv1);
+				hist_finish(w, plane, t, lane, val1, ok1, nv1);
+			}
+			return;
+		}
+	}
+	const int hist_tiles = w.NT;
 	int val[HIST_TPW][16], nvalid[HIST_TPW];
 	unsigned ok[HIST_TPW];
 #pragma unroll
 	for (int u = 0; u < HIST_TPW; ++u)
-		if (tile0 + u < w.NT)   // uniform
+		if (tile0 + u < hist_tiles)   // uniform
 			hist_load(g, lin, plane, tile0 + u, lane, val[u], ok[u], nvalid[u]);
 #pragma unroll
 	for (int u = 0; u < HIST_TPW; ++u)
-		if (tile0 + u < w.NT)
+		if (tile0 + u < hist_tiles)
 			hist_finish(w, plane, tile0 + u, lane, val[u], ok[u], nvalid[u]);
 }
 
@@ -468,21 +506,14 @@ __global__ __launch_bounds__(1024) void k_plan(PackGeom g, const int *__restrict
 	if (threadIdx.x < 3)
 		top_of[threadIdx.x] = 0;
 	__syncthreads();
-	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count: maximum over its tiles (k_hist left one byte per tile, rows padded to 16)
-		const uint4 *tt = reinterpret_cast<const uint4 *>(w.tile_top + (long)(img * g.C + c) * w.NTP);
-		unsigned m = 0;   // byte-wise maximum of 16 tiles at a time
-		for (int q = threadIdx.x; q * 16 < w.NT; q += blockDim.x) {
+	for (int c = 0; c < g.C; ++c) {   // the plane's bit-plane count from the OR of all its magnitudes (one word per tile, rows padded to 4 and zero there)
+		const uint4 *tt = reinterpret_cast<const uint4 *>(w.tile_mx + (long)(img * g.C + c) * w.NTP);
+		unsigned m = 0;
+		for (int q = threadIdx.x; q * 4 < w.NT; q += blockDim.x) {
 			const uint4 v = tt[q];
-			const unsigned x[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-			for (int u = 0; u < 4; ++u)
-#pragma unroll
-				for (int bb = 0; bb < 4; ++bb) {
-					const unsigned e = (x[u] >> (8 * bb)) & 0xffu;
-					m = q * 16 + u * 4 + bb < w.NT ? max(m, e) : m;
-				}
+			m |= v.x | (q * 4 + 1 < w.NT ? v.y : 0u) | (q * 4 + 2 < w.NT ? v.z : 0u) | (q * 4 + 3 < w.NT ? v.w : 0u);
 		}
-		int top = (int)m;
+		int top = m ? ilog2u(m) + 1 : 0;
 		for (int o = 32; o; o >>= 1)
 			top = max(top, __shfl_xor(top, o));
 		if ((threadIdx.x & 63) == 0)
@@ -1186,7 +1217,8 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 	// Coded planes at or above the tile's own bit-plane count see nothing but zeros: no tokens, no refinement bits, the
 	// tile just hands its coefficients on to the run counter (k_carry_*).  When that is all there is — the finest
 	// rings' high planes under a CAPACITY that cut the low ones off — the coefficients are not even loaded.
-	const int tile_top = w.tile_top[(long)plane * w.NTP + tile];
+	const unsigned tile_or = w.tile_mx[(long)plane * w.NTP + tile];
+	const int tile_top = tile_or ? ilog2u(tile_or) + 1 : 0;
 	if (!(live & ((1u << (tile_top < 31 ? tile_top : 31)) - 1u))) {   // uniform
 		if (lane < MAX_PLANES && ((live >> lane) & 1u)) {
 			const int k = w.segidx[((long)img * 48 + c * 16 + l) * MAX_PLANES + lane] - 1;
@@ -2204,21 +2236,13 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" int dwtx_encode_planes(dwtx_ctx *ctx, const int32_t *lin, int W, int H, int C, int n, long capacity,
 	uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
 {
-	return dwtx_encode_planes_ex(ctx, lin, nullptr, 0u, W, H, C, n, capacity, out, out_stride, dev_info);
+	return dwtx_encode_planes_ex(ctx, lin, nullptr, 0u, 0u, W, H, C, n, capacity, out, out_stride, dev_info);
 }
 
-// pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
-// 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
-int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, int W, int H, int C, int n,
-	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
+// geometry, tiles and the histogram records of n images (what both the forward transform's histograms and the
+// entropy stage start from)
+static int pack_geometry(dwtx_ctx *ctx, int W, int H, int C, int n, PackGeom &g, Work &w, dwtx_tiles &tiles)
 {
-	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
-		return DWTX_ERR_ARG;
-	DWTX_ENTER(ctx);
-	DWTX_CHECK_DIMS(W, H);
-	if (sq_levels && (!pyr || (sq_levels & ~dwtx_square_levels(W, H)) || ((uintptr_t)pyr & 15)))
-		return DWTX_ERR_ARG;
-	PackGeom g;
 	{
 		int lengths[DWTX_MAX_LEVELS], pixels[DWTX_MAX_LEVELS], widths[DWTX_MAX_LEVELS], heights[DWTX_MAX_LEVELS];
 		g.levels = dwtx_compute_lengths(lengths, pixels, widths, heights, W, H, DWTX_MIN_LEN);
@@ -2228,29 +2252,82 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 			g.side[l] = lengths[l + 1];
 		g.side[g.levels] = 0;
 	}
-	g.pyr = pyr;
-	g.sq_levels = sq_levels;
+	g.pyr = nullptr;
+	g.sq_levels = 0;
 	g.C = C;
 	g.W = W;
 	g.H = H;
 	g.total = (long)W * H;
-	dwtx_tiles tiles;
-	{
-		const int rc = dwtx_get_tiles(ctx, W, H, &tiles);
-		if (rc)
-			return rc;
-	}
-	const int NT = tiles.NT;
+	const int rc = dwtx_get_tiles(ctx, W, H, &tiles);
+	if (rc)
+		return rc;
 	for (int l = 0; l <= g.levels; ++l)
 		g.tile_first[l] = tiles.tile_first[l];
 	g.tile_base = tiles.base;
 	g.tile_cnt = tiles.cnt;
 	g.tile_blk = tiles.blk;
-
-	Work w;
 	memset(&w, 0, sizeof(w));
-	w.NT = NT;
-	w.NTP = (NT + 15) / 16 * 16;
+	w.NT = tiles.NT;
+	w.NTP = (tiles.NT + 3) / 4 * 4;
+	const size_t b = align_up(sizeof(unsigned short) * (size_t)n * C * w.NT * NCUM, 256);
+	w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b + sizeof(unsigned) * (size_t)n * C * w.NTP);
+	if (!w.cum)
+		return DWTX_ERR_NOMEM;
+	w.tile_mx = (unsigned *)((char *)w.cum + b);
+	return DWTX_OK;
+}
+
+// The forward transform of the same n images, queued after this on the context's stream, adds the histograms of the
+// levels it can take to these records (lift.hip); dwtx_encode_planes_ex is then told which levels are done.
+int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *sink)
+{
+	if (!ctx || !sink || (C != 1 && C != 3) || n < 1 || n > 65535)
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	DWTX_CHECK_DIMS(W, H);
+	PackGeom g;
+	Work w;
+	dwtx_tiles tiles;
+	const int rc = pack_geometry(ctx, W, H, C, n, g, w, tiles);
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(k_hist_init, dim3(dwtx_cdiv(w.NT * (NCUM / 2), 256), n * C), dim3(256), 0, ctx->stream, g, w);
+	DWTX_LAUNCH_CHECK();
+	sink->cum32 = reinterpret_cast<unsigned *>(w.cum);
+	sink->tile_mx = w.tile_mx;
+	sink->NT = w.NT;
+	sink->NTP = w.NTP;
+	sink->tiles = tiles;
+	return DWTX_OK;
+}
+
+// pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
+// 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
+int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C,
+	int n, long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
+{
+	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	DWTX_CHECK_DIMS(W, H);
+	if (sq_levels && (!pyr || (sq_levels & ~dwtx_square_levels(W, H)) || ((uintptr_t)pyr & 15)))
+		return DWTX_ERR_ARG;
+	PackGeom g;
+	Work w;
+	dwtx_tiles tiles;
+	{
+		const int rc = pack_geometry(ctx, W, H, C, n, g, w, tiles);   // (the records dwtx_hist_begin handed out, if it was called: same slot, same size)
+		if (rc)
+			return rc;
+	}
+	g.pyr = pyr;
+	g.sq_levels = sq_levels;
+	const int NT = tiles.NT;
+	// k_hist counts the tiles of the levels the forward transform has not done; when those are the coarse levels only (the
+	// finest ones are a suffix of the tiles) its grid ends there
+	int hist_tiles = NT;
+	for (int l = g.levels - 1; l >= 0 && ((hist_levels >> l) & 1u); --l)
+		hist_tiles = tiles.tile_first[l];
 	w.ES = (long)NT * C * MAX_PLANES + 16;
 	w.TS = ((long)C * (g.total - g.pixels[0]) + MAX_SEGS + 8 + 63) / 64 * 64;   // multiple of 64: every image's token arrays start vector-aligned
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
@@ -2262,9 +2339,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 
 	// carve scratch
 	{
-		size_t b = align_up(sizeof(unsigned short) * (size_t)nplanes * NT * NCUM, 256);
-		w.cum = (unsigned short *)dwtx_scratch(ctx, SLOT_PK_CUM, b + (size_t)nplanes * w.NTP);
-		w.tile_top = (unsigned char *)w.cum + b;
 		size_t off = 0;
 		auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 		const size_t o_info = take(sizeof(ImgInfo) * n);
@@ -2279,7 +2353,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		const size_t o_sx = take(sizeof(int) * (size_t)n * 48 * MAX_PLANES);
 		const size_t o_lv = take(sizeof(unsigned) * (size_t)n * 48);
 		char *small = (char *)dwtx_scratch(ctx, SLOT_PK_SMALL, off);
-		if (!w.cum || !small)
+		if (!small)
 			return DWTX_ERR_NOMEM;
 		w.info = (ImgInfo *)(small + o_info);
 		w.slow = (int *)(small + o_slow);
@@ -2356,7 +2430,8 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	// k_plan stores the first words (header, root image, plane counts) outright; the rest of the stream is
 	// cleared by k_clear_stream once its length is known
 
-	hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(NT, 4 * HIST_TPW), nplanes), dim3(256), 0, s, g, lin, w);
+	if (hist_tiles > 0)
+		hipLaunchKernelGGL(k_hist, dim3(dwtx_cdiv(hist_tiles, 4 * HIST_TPW), nplanes), dim3(256), 0, s, g, lin, w, hist_levels);
 	hipLaunchKernelGGL(k_plan, dim3(n), dim3(1024), 0, s, g, lin, w, outw, out_words, capacity);
 	hipLaunchKernelGGL(k_entries_count, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, g, w);
 	hipLaunchKernelGGL(k_entries_blocks, dim3(n), dim3(ENT_BLOCK), 0, s, w);
