@@ -540,8 +540,8 @@ def main():
         ctx = dwt_amd.Context(local)
         one = Runner(ctx, torch, dwt_amd, "gray4096", 1, 0, 1, dev)
         t1, (s1, l1, d1, i1), _ = one.timed(5, 2, fence)
-        em, _ = timed(lambda: ctx.encode_device(one.pix, out=one.out[0], info=one.info[0]))
-        dm, _ = timed(lambda: ctx.decode_device(one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, out=one.dec))
+        em = min(timed(lambda: ctx.encode_device(one.pix, out=one.out[0], info=one.info[0]))[0] for _ in range(3))
+        dm = min(timed(lambda: ctx.decode_device(one.out[0], ctx.stream_lengths(one.info[0]), 4096, 4096, 1, out=one.dec))[0] for _ in range(3))
         result["single_frame"] = {
             "workload": "one 4096x4096x1 frame per step (BASELINE.json configs[1] literally)",
             "value": round(5 * 4096 * 4096 / t1 / 1e6, 1), "unit": "Mpixels/s",
@@ -581,25 +581,35 @@ def main():
             t2, (s2, l2, d2, i2), _ = r2.timed(XS, 2, fence)
             ok2 = bool(torch.equal(d2.view(r2.B, r2.H, r2.W, r2.C), r2.pix)) and all(i.status == 0 and not i.truncated for i in i2)
             g2 = golden_check(name, s2[0, : int(l2[0])].cpu().numpy().tobytes())
-            pl = cx.planes_from_pixels(r2.pix)
-            lin2 = cx.linearization(cx.transformation_fwd(pl))
-            del pl
-            cr = coder_record(cx, torch, dwt_amd, lin2, r2.W, r2.H, r2.C, r2.B, r2.stride, dev, reps=1)
-            del lin2
-            extras[name] = {
+            rec = {
                 "workload": f"{r2.W}x{r2.H}x{r2.C}, {r2.B} frames per step, {XS} steps ({CONFIG_OF[name]})",
                 "value": round(XS * r2.B * r2.W * r2.H / t2 / 1e6, 1), "unit": "Mpixels/s",
                 "Msamples_per_s": round(XS * r2.B * r2.W * r2.H * r2.C / t2 / 1e6, 1),
                 "ms_per_step": round(t2 / XS * 1e3, 3), "bytes_per_frame": int(l2.sum().item() / r2.B),
                 "roundtrip_lossless": ok2, "stream0_matches_reference_golden": g2,
-                "coder_encode_frac_of_hbm_peak": cr["encode"]["frac_of_hbm_peak"],
-                "coder_decode_frac_of_hbm_peak": cr["decode"]["frac_of_hbm_peak"],
-                "coder_encode_ms": cr["encode"]["ms_per_step"], "coder_decode_ms": cr["decode"]["ms_per_step"],
                 "sidecar_index": with_index(cx, r2.out[0], cx.stream_lengths(r2.info[0]), r2.W, r2.H, r2.C, r2.B, r2.dec, r2.pix),
             }
+            # the entropy stage alone, on a context of its own once the workload's scratch is given back (at most 256 frames:
+            # the three planes-sized tensors of the staged path would not fit beside a thousand frames' scratch)
+            nb = min(r2.B, 256)
+            cpix = r2.pix[:nb].clone()
+            geo = (r2.W, r2.H, r2.C, r2.stride)
             del r2, s2, d2
             cx.close()
             del cx
+            torch.cuda.empty_cache()
+            cy = dwt_amd.Context(local)
+            pl = cy.planes_from_pixels(cpix)
+            lin2 = cy.linearization(cy.transformation_fwd(pl))
+            del pl
+            cr = coder_record(cy, torch, dwt_amd, lin2, geo[0], geo[1], geo[2], nb, geo[3], dev, reps=1)
+            del lin2, cpix
+            cy.close()
+            del cy
+            rec.update({"coder_frames": nb, "coder_encode_frac_of_hbm_peak": cr["encode"]["frac_of_hbm_peak"],
+                        "coder_decode_frac_of_hbm_peak": cr["decode"]["frac_of_hbm_peak"],
+                        "coder_encode_ms": cr["encode"]["ms_per_step"], "coder_decode_ms": cr["decode"]["ms_per_step"]})
+            extras[name] = rec
         torch.cuda.empty_cache()
         extras["rgb16384_cap1MiB"] = capacity_record(dwt_amd, torch, local, timed)
         result["workloads"] = extras

@@ -535,19 +535,51 @@ __device__ __forceinline__ void xcd_strip(int &bx, int &by)
 	}
 }
 
+// The RGB source: every plane's workgroup reads all three bytes of its pixels, so the three channels of a strip are
+// made neighbours in time ON ONE XCD (grid.x holds three workgroups per strip, grid.z the images): the second and the
+// third find the pixels in that XCD's L2 instead of fetching them from HBM again.
+__device__ __forceinline__ void xcd_strip_rgb(int &bx, int &by, int &c)
+{
+	const int gx = gridDim.x / 3, n = gx * gridDim.y;
+	const int d = blockIdx.x + gridDim.x * blockIdx.y;   // 0 .. 3n-1; workgroup d runs on XCD d mod 8
+	int s;
+	if ((n & 7) == 0) {
+		const int slot = d >> 3;
+		s = (d & 7) * (n >> 3) + slot / 3;
+		c = slot % 3;
+	} else {
+		s = d / 3;
+		c = d % 3;
+	}
+	by = s / gx;
+	bx = s - by * gx;
+}
+
+template <typename SrcT>
+struct IsRgb {
+	static constexpr bool value = false;
+};
+template <>
+struct IsRgb<Rgb8> {
+	static constexpr bool value = true;
+};
+
 template <typename SrcT, bool HIST>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int bx, by;
-	xcd_strip(bx, by);
+	int bx, by, chan = 0;
+	if (IsRgb<SrcT>::value)
+		xcd_strip_rgb(bx, by, chan);
+	else
+		xcd_strip(bx, by);
 	const int q = bx * 64 + lane;
 	const int j0 = (by * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
-	const int plane = blockIdx.z;
+	const int plane = IsRgb<SrcT>::value ? (int)blockIdx.z * 3 + chan : (int)blockIdx.z;
 	const bool valid = q < A.nquads;
 	int ch;
 	const typename SrcElem<SrcT>::type *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
@@ -1296,6 +1328,7 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			A.a = a;
 			A.hist = HistArgs{ nullptr, nullptr, nullptr, 0, 0, 0 };
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
+			dim3 rgb_grid(sx * 3, grid.y, nplanes / 3);   // the three channels of a strip side by side (xcd_strip_rgb)
 			if (hist_here) {
 				A.hist.cum32 = sink->cum32;
 				A.hist.tile_mx = sink->tile_mx;
@@ -1305,13 +1338,13 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 				A.hist.nbs = sink->tiles.nbs[level];
 				*hist_levels |= 1u << level;
 				if (bytes_in && in8_channels == 3)
-					hipLaunchKernelGGL((k_fwd_level_w<Rgb8, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+					hipLaunchKernelGGL((k_fwd_level_w<Rgb8, true>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else if (bytes_in)
 					hipLaunchKernelGGL((k_fwd_level_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else
 					hipLaunchKernelGGL((k_fwd_level_w<int, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			} else if (bytes_in && in8_channels == 3)
-				hipLaunchKernelGGL((k_fwd_level_w<Rgb8, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_level_w<Rgb8, false>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_in)
 				hipLaunchKernelGGL((k_fwd_level_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else

@@ -871,12 +871,15 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_cut(Work w, long capacity, int cu
 // DPP scan of the same counts widened to 16-bit fields.  Tokens of plane p take the tile's slots
 // [#(t >= p+2), #(t >= p+1)): plane-major, in coefficient order — the order of the stream.
 
-constexpr int TABP = 18;             // dwords per lane in the class table (9 pairs: ds_read_b64 conflict-free over 32 lanes)
+// The class table is laid out class by class, the 64 lanes of a class side by side: whatever class a lane asks for, its
+// bank is its lane's — look-ups never conflict, and nothing is padded (4 KB per wave: six workgroups fit a CU).
+__device__ __forceinline__ int tab8(int lane, int cls) { return cls * 128 + lane * 2; }    // up to 8 planes: two dwords per entry
+__device__ __forceinline__ int tab16(int lane, int cls) { return cls * 64 + lane; }        // more: one
 constexpr int ROWW = 34;             // words per staging row of one plane (31 + 1024 bits + slack)
 
 struct alignas(16) CodeLds {
-	unsigned tab[64 * TABP];         // up to 8 planes: [lane][t-1][2] = { Z[t-1],  first slot of plane t-1 + Z[t] - Z[t-1] };
-	                                 // more: [lane][t-1] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
+	unsigned tab[1024];              // up to 8 planes: [t-1][lane][2] = { Z[t-1],  first slot of plane t-1 + Z[t] - Z[t-1] };
+	                                 // more: [t-1][lane] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
 	union {                          // (the token slots have left for memory before the refinement rows are gathered)
 		unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 12, then turned into tokens in place
 		unsigned rows[(MAX_PLANES - 1) * ROWW];
@@ -956,7 +959,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 
 	// ---- pass A: magnitudes, signs, per-lane counts of (t <= q) as nibbles (two halves: a nibble holds up to 8) ----
 	unsigned mag[16];
-	int tt[16];
 	unsigned sgn = 0;
 	R_t Ra = 0, Rb = 0;
 #pragma unroll
@@ -967,7 +969,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		sgn |= ((unsigned)v >> 31) << i;
 		int t = 32 - __clz((int)a);
 		t = t < NQ ? t : NQ;
-		tt[i] = t;
 		const int te = FULL || i < nv ? t : NQ;   // past the end: counted nowhere
 		const R_t m = te < NQ ? ONES << (4 * te) : (R_t)0;
 		if (i < 8)
@@ -1005,9 +1006,9 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 			const unsigned zhi = t < NQ && t < P ? ZL(t) : (unsigned)vb;   // (no coefficient of this tile has more than P bits)
 			const unsigned ct = t < NQ && t < P ? CT(t) : (unsigned)nvalid;
 			if (NQ == 8)
-				*reinterpret_cast<uint2 *>(&L.tab[lane * TABP + 2 * (t - 1)]) = make_uint2(zlo, (unsigned)nvalid - ct + zhi - zlo);
+				*reinterpret_cast<uint2 *>(&L.tab[tab8(lane, t - 1)]) = make_uint2(zlo, (unsigned)nvalid - ct + zhi - zlo);
 			else
-				L.tab[lane * TABP + t - 1] = zlo | (zhi - zlo) << 10 | ((unsigned)nvalid - ct) << 20;
+				L.tab[tab16(lane, t - 1)] = zlo | (zhi - zlo) << 10 | ((unsigned)nvalid - ct) << 20;
 		}
 	}
 	if (lane == 0) {
@@ -1028,17 +1029,18 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 			uint2 ent[NB8];
 #pragma unroll
 			for (int i = NB8 * h; i < NB8 * h + NB8; ++i) {   // a batch of table look-ups first: their latencies overlap
-				const int tm = tt[i] > 0 ? tt[i] - 1 : 0;
+				const int t0 = min(32 - __clz((int)mag[i]), NQ);   // (the bit count again: sixteen registers less than keeping it)
+				const int tm = t0 > 0 ? t0 - 1 : 0;
 				if (NQ == 8) {
-					ent[i % NB8] = *reinterpret_cast<const uint2 *>(&L.tab[lane * TABP + 2 * tm]);
+					ent[i % NB8] = *reinterpret_cast<const uint2 *>(&L.tab[tab8(lane, tm)]);
 				} else {
-					const unsigned e = L.tab[lane * TABP + tm];
+					const unsigned e = L.tab[tab16(lane, tm)];
 					ent[i % NB8] = make_uint2(e & 0x3ffu, (e >> 20) + ((e >> 10) & 0x3ffu));
 				}
 			}
 #pragma unroll
 			for (int i = NB8 * h; i < NB8 * h + NB8; ++i) {
-				const int t = tt[i];
+				const int t = min(32 - __clz((int)mag[i]), NQ);
 				const int tm = t > 0 ? t - 1 : 0;
 				const unsigned x = (unsigned)(R >> (4 * tm));
 				const unsigned lz_lo = x & 15u;
@@ -1117,7 +1119,7 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 	wave_sync();
 	// the lane's string of plane p at its place in the plane's row
 	auto deposit = [&](int p, unsigned acc, unsigned cnt) {
-		const unsigned zl = L.tab[lane * TABP + (NQ == 8 ? 2 : 1) * (p + 1)] & 0x3ffu;   // Z[p+1] of the lanes before
+		const unsigned zl = L.tab[NQ == 8 ? tab8(lane, p + 1) : tab16(lane, p + 1)] & 0x3ffu;   // Z[p+1] of the lanes before
 		const unsigned pos = (unsigned)(L.rb[p] & 31ull) + ((unsigned)vb - zl);
 		if (cnt) {
 			unsigned *row = L.rows + p * ROWW;
