@@ -48,6 +48,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef DWTX_PROF_SECTIONS   // experiment builds: cycles per section of k_code, summed over waves (tools only, never shipped)
+__device__ unsigned long long g_prof[16];
+extern "C" void dwtx_debug_prof(unsigned long long *out, int reset)
+{
+	if (out)
+		(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+	if (reset) {
+		unsigned long long z[16] = { 0 };
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+	}
+}
+#define PROF_MARK(k) do { const unsigned long long t_now_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_prof[k], t_now_ - t_prof_); t_prof_ = t_now_; } while (0)
+#define PROF_BEGIN() unsigned long long t_prof_ = __builtin_readcyclecounter()
+#else
+#define PROF_MARK(k)
+#define PROF_BEGIN()
+#endif
+
 namespace {
 
 constexpr int TILE = 1024;
@@ -110,7 +128,6 @@ struct Work {
 	int *seg_ebase;             // [n][MAX_SEGS+1]
 	unsigned *seg_refs;         // [n][MAX_SEGS]
 	unsigned long long *seg_rawoff; // [n][MAX_SEGS] bit offset of the segment's refinement block in the stream
-	unsigned long long *seg_stage;  // [n][MAX_SEGS+1] word offset of the segment's refinement block in the staging buffer
 	unsigned *brk_tok;          // [n][MAX_SEGS] token index of the segment's break slot
 	int *segidx;                // [n][3][16][MAX_PLANES] -> k+1 of the segment coding (channel, level, plane)
 	unsigned *live;             // [n][3][16] bit p: plane p of (channel, level) is coded (its segment starts inside CAPACITY; k_cut)
@@ -119,6 +136,7 @@ struct Work {
 	unsigned short *ent_seg;    // [n][ES] the entry's segment (k_entries_count looks it up once)
 	unsigned *ent_tokbase;      // [n][ES+1]
 	unsigned *ent_refscum;      // [n][ES+1]
+	unsigned *ent_refw;         // [n][ES+1] first word of the entry's refinement bits in the staging buffer (every entry starts on a word)
 	// per token
 	unsigned short *tok16;      // [n][TS]
 	unsigned *tok_big;          // [n][TS] only touched where tok16 says T_ESC
@@ -136,7 +154,7 @@ struct Work {
 	unsigned long long *chunk_base;    // [n][NCS]
 	RunMap *carry_agg;                 // [n][NCB] map of each block of 1024 entries
 	unsigned *carry_in;                // [n][NCB] pending run entering the block
-	unsigned *ent_blk;                 // [n][NCB][2] token slots / refinement bits of each block of 1024 entries, then their scan
+	unsigned *ent_blk;                 // [n][NCB][3] token slots / refinement bits / staging words of each block of 1024 entries, then their scan
 	unsigned long long *stream_bits;   // [n] bits of the whole stream before any capacity clip (k_bitscan -> k_clear_stream)
 	int *slow;                         // [n] set when the fast order pass could not resolve an image
 	long ES, TS, NCS, NGS, NCB, SW;
@@ -704,16 +722,19 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_count(PackGeom g, Work w)
 		nt = (unsigned)(upto - z) + (j == ntile - 1 ? 1u : 0u);   // + the segment's break slot
 		nr = (unsigned)(cnt - upto);
 	}
-	unsigned tt, rt;
+	unsigned tt, rt, wt;
 	const unsigned tb = block_excl_scan(nt, wsum, tt);
 	const unsigned rb = block_excl_scan(nr, wsum, rt);
+	const unsigned wb = block_excl_scan((nr + 31u) >> 5, wsum, wt);
 	if (e < E) {
 		w.ent_tokbase[img * (w.ES + 1) + e] = tb;
 		w.ent_refscum[img * (w.ES + 1) + e] = rb;
+		w.ent_refw[img * (w.ES + 1) + e] = wb;
 	}
 	if (threadIdx.x == 0) {
-		w.ent_blk[(img * w.NCB + blockIdx.x) * 2] = tt;
-		w.ent_blk[(img * w.NCB + blockIdx.x) * 2 + 1] = rt;
+		w.ent_blk[(img * w.NCB + blockIdx.x) * 3] = tt;
+		w.ent_blk[(img * w.NCB + blockIdx.x) * 3 + 1] = rt;
+		w.ent_blk[(img * w.NCB + blockIdx.x) * 3 + 2] = wt;
 	}
 }
 
@@ -724,24 +745,28 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_blocks(Work w)
 	ImgInfo &I = w.info[img];
 	const int E = I.E;
 	const int nb = (E + ENT_BLOCK - 1) / ENT_BLOCK;
-	unsigned tok_run = 0, ref_run = 0;
+	unsigned tok_run = 0, ref_run = 0, word_run = 0;
 	for (int b0 = 0; b0 < nb; b0 += ENT_BLOCK) {
 		const int b = b0 + threadIdx.x;
-		unsigned *slot = w.ent_blk + (img * w.NCB + b) * 2;
-		const unsigned t = b < nb ? slot[0] : 0u, r = b < nb ? slot[1] : 0u;
-		unsigned tt, rt;
+		unsigned *slot = w.ent_blk + (img * w.NCB + b) * 3;
+		const unsigned t = b < nb ? slot[0] : 0u, r = b < nb ? slot[1] : 0u, wd = b < nb ? slot[2] : 0u;
+		unsigned tt, rt, wt;
 		const unsigned tb = block_excl_scan(t, wsum, tt);
 		const unsigned rb = block_excl_scan(r, wsum, rt);
+		const unsigned wb = block_excl_scan(wd, wsum, wt);
 		if (b < nb) {
 			slot[0] = tok_run + tb;
 			slot[1] = ref_run + rb;
+			slot[2] = word_run + wb;
 		}
 		tok_run += tt;
 		ref_run += rt;
+		word_run += wt;
 	}
 	if (threadIdx.x == 0) {
 		w.ent_tokbase[img * (w.ES + 1) + E] = tok_run;
 		w.ent_refscum[img * (w.ES + 1) + E] = ref_run;
+		w.ent_refw[img * (w.ES + 1) + E] = word_run;
 		I.T = tok_run + 1;   // + final flush (encode.c:221)
 	}
 }
@@ -752,55 +777,26 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_entries_finish(Work w)
 	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
 	if (e >= w.info[img].E)
 		return;
-	const unsigned *slot = w.ent_blk + (img * w.NCB + blockIdx.x) * 2;
+	const unsigned *slot = w.ent_blk + (img * w.NCB + blockIdx.x) * 3;
 	w.ent_tokbase[img * (w.ES + 1) + e] += slot[0];
 	w.ent_refscum[img * (w.ES + 1) + e] += slot[1];
+	w.ent_refw[img * (w.ES + 1) + e] += slot[2];
 }
 
 __global__ __launch_bounds__(ENT_BLOCK) void k_entries_segs(Work w)
 {
-	__shared__ unsigned wsum[16];
 	const int img = blockIdx.x;
 	const int K = w.info[img].K;
 	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
 	const unsigned *tokbase = w.ent_tokbase + img * (w.ES + 1), *refscum = w.ent_refscum + img * (w.ES + 1);
 	static_assert(MAX_SEGS <= ENT_BLOCK, "one thread per segment");
 	const int k = threadIdx.x;
-	unsigned words = 0;
 	if (k < K) {
 		const unsigned refs = refscum[eb[k + 1]] - refscum[eb[k]];
 		w.seg_refs[(long)img * MAX_SEGS + k] = refs;
 		const int last = eb[k + 1] - 1;
 		w.brk_tok[(long)img * MAX_SEGS + k] = tokbase[last] + w.ent_ones[img * w.ES + last];
-		words = (refs + 31u) >> 5;
 	}
-	// every segment's refinement block starts on a word of the staging buffer (at most 2^31 bits each)
-	unsigned total;
-	const unsigned at = block_excl_scan(words, wsum, total);
-	if (k <= K && k <= MAX_SEGS)
-		w.seg_stage[(long)img * (MAX_SEGS + 1) + k] = at;
-}
-
-// k_code writes the first and the last staging word of an entry's refinement bits with atomicOr (they are
-// shared with the neighbouring entries) and the words between with plain stores: only the shared ones must
-// start as zeros.
-__global__ __launch_bounds__(ENT_BLOCK) void k_stage_zero(Work w)
-{
-	const int img = blockIdx.y;
-	const ImgInfo &I = w.info[img];
-	const int e = blockIdx.x * ENT_BLOCK + threadIdx.x;
-	if (e >= I.E)
-		return;
-	const unsigned refs = w.ent_refs[img * w.ES + e];
-	if (!refs)
-		return;
-	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
-	const int k = w.ent_seg[img * w.ES + e];
-	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
-	const unsigned long long bit0 = (w.seg_stage[(long)img * (MAX_SEGS + 1) + k] << 5) + (refscum[e] - refscum[eb[k]]);
-	unsigned *st = w.stage + img * w.SW;
-	st[bit0 >> 5] = 0u;
-	st[(bit0 + refs - 1) >> 5] = 0u;
 }
 
 // ------------------------------------------------------------------- k_cut ---
@@ -876,16 +872,21 @@ __global__ __launch_bounds__(ENT_BLOCK) void k_cut(Work w, long capacity, int cu
 __device__ __forceinline__ int tab8(int lane, int cls) { return cls * 128 + lane * 2; }    // up to 8 planes: two dwords per entry
 __device__ __forceinline__ int tab16(int lane, int cls) { return cls * 64 + lane; }        // more: one
 constexpr int ROWW = 34;             // words per staging row of one plane (31 + 1024 bits + slack)
+// Token slots of a tile: its planes' tokens one plane after the other, highest plane first — each plane's first slot
+// moved up by at most 7 so that it sits like the plane's first token in memory modulo 8 (the tokens then leave as
+// 16-byte pieces, LDS and memory aligned alike) — plus 8 dummy slots for the zero coefficients' writes.
+constexpr int ZS_DUMMY = TILE + 8 * MAX_PLANES, ZS_SLOTS = ZS_DUMMY + 8;
 
 struct alignas(16) CodeLds {
 	unsigned tab[1024];              // up to 8 planes: [t-1][lane][2] = { Z[t-1],  first slot of plane t-1 + Z[t] - Z[t-1] };
 	                                 // more: [t-1][lane] = Z[t-1] | (Z[t]-Z[t-1]) << 10 | (first slot of plane t-1) << 20
 	union {                          // (the token slots have left for memory before the refinement rows are gathered)
-		unsigned short zs[TILE + 8];     // token slots: zeros before (10 bits) | sign << 12, then turned into tokens in place
+		unsigned short zs[ZS_SLOTS];     // token slots: zeros before (10 bits) | sign << 12, then turned into tokens in place
 		unsigned rows[(MAX_PLANES - 1) * ROWW];
 	};
 	unsigned short cum[MAX_PLANES + 2];   // the tile's histogram: #(t <= q), q = 0..16
-	unsigned gb[MAX_PLANES];         // plane p: token index of the entry's first token minus the plane's first slot; ~0: plane not coded
+	unsigned short slot0[MAX_PLANES];     // plane p's first token slot
+	unsigned gb[MAX_PLANES];         // (16-plane variant) plane p: token index of the entry's first token; ~0: plane not coded
 	unsigned long long rb[MAX_PLANES];    // plane p: bit position of the entry's refinement bits in the staging buffer
 	int ent[MAX_PLANES];             // plane p: entry index, -1 = the plane is not coded for this tile
 };
@@ -953,6 +954,7 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 {
 	// Planes at or above the tile's own bit-plane count hold nothing but zeros here: all per-class work stops at P
 	const int P = Pc < tile_top ? Pc : tile_top;
+	PROF_BEGIN();
 	typedef typename Nib<NQ>::T R_t;
 	constexpr R_t ONES = Nib<NQ>::ONES, M0F = Nib<NQ>::M0F;
 	constexpr int NB = NQ / 4;   // dwords of 16-bit fields per parity
@@ -996,30 +998,148 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		E[b] = ei - e0;   // exclusive: the lanes before this one
 		O[b] = oi - o0;
 	}
+	PROF_MARK(1);   // pass A + scans
 	// Z over the lanes before me / the whole tile, q a compile-time constant after unrolling
 #define ZL(q) ((((q) & 1 ? O[((q) >> 2) % NB] : E[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
 #define CT(q) ((((q) & 1 ? cO[((q) >> 2) % NB] : cE[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
+	// every plane's first slot (uniform; planes descending = slots ascending)
+	unsigned first[NQ];
+	{
+		unsigned cur = 0;
+#pragma unroll
+		for (int p = NQ - 1; p >= 0; --p) {
+			const unsigned c1 = p + 1 < P && p + 1 < NQ ? CT(p + 1) : (unsigned)nvalid, c0 = p < P ? CT(p) : (unsigned)nvalid;
+			const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)my_tokbase, p);
+			first[p] = cur + ((tb - cur) & 7u);
+			cur = first[p] + (c1 - c0);
+		}
+	}
 #pragma unroll
 	for (int t = 1; t <= NQ; ++t) {
 		if (t <= P) {
 			const unsigned zlo = ZL(t - 1);
 			const unsigned zhi = t < NQ && t < P ? ZL(t) : (unsigned)vb;   // (no coefficient of this tile has more than P bits)
-			const unsigned ct = t < NQ && t < P ? CT(t) : (unsigned)nvalid;
 			if (NQ == 8)
-				*reinterpret_cast<uint2 *>(&L.tab[tab8(lane, t - 1)]) = make_uint2(zlo, (unsigned)nvalid - ct + zhi - zlo);
+				*reinterpret_cast<uint2 *>(&L.tab[tab8(lane, t - 1)]) = make_uint2(zlo, first[t - 1] + zhi - zlo);
 			else
-				L.tab[tab16(lane, t - 1)] = zlo | (zhi - zlo) << 10 | ((unsigned)nvalid - ct) << 20;
+				L.tab[tab16(lane, t - 1)] = zlo | (zhi - zlo) << 10 | first[t - 1] << 20;
 		}
 	}
 	if (lane == 0) {
 #pragma unroll
 		for (int q = 0; q <= MAX_PLANES; ++q)
 			L.cum[q] = (unsigned short)(q < P && q < NQ ? CT(q) : (unsigned)nvalid);
+#pragma unroll
+		for (int q = 0; q < MAX_PLANES; ++q)
+			L.slot0[q] = (unsigned short)(q < NQ ? first[q < NQ ? q : 0] : 0u);
 	}
-#undef ZL
-#undef CT
+	wave_sync();
+	PROF_MARK(2);   // table
+
+	// per-plane facts of the tile for the plane loops below (lane p holds plane p's)
+	if (lane < MAX_PLANES) {
+		L.gb[lane] = my_ent >= 0 ? my_tokbase : ~0u;
+		L.ent[lane] = my_ent;
+		L.rb[lane] = my_rb;
+	}
 	wave_sync();
 
+	auto cq = [&](int q) -> unsigned { return q < P && q < NQ ? CT(q) : (unsigned)nvalid; };   // q a constant
+
+	// The refinement bits go first: their last step adds the rows' edge words to the staging buffer with global atomics
+	// (the neighbouring tiles share those words), which take long to come back — issued here, they have the
+	// whole token stage to do so; issued last they held the finished wave's slot (a quarter of this kernel's time).
+	// ---- pass C: refinement bits (encode.c:84-93), per plane a <= 16-bit string per lane at rank (coefficients before) - Z[p+1] ----
+	wave_sync();
+	for (int i = lane; i < (NQ - 1) * ROWW; i += 64)
+		L.rows[i] = 0u;
+	wave_sync();
+	PROF_MARK(6);   // rows zeroed
+	// the lane's string of plane p at its place in the plane's row: zl = Z[p+1] of the lanes before, bit0 = where the entry's bits start
+	auto deposit = [&](int p, unsigned acc, unsigned cnt, unsigned zl, unsigned bit0) {
+		const unsigned pos = (bit0 & 31u) + ((unsigned)vb - zl);
+#ifndef EXP_NODEPOSIT
+		if (cnt) {
+			unsigned *row = L.rows + p * ROWW;
+			const unsigned sh = pos & 31u;
+			atomicOr(&row[pos >> 5], acc << sh);
+			if (sh + cnt > 32u)
+				atomicOr(&row[(pos >> 5) + 1], acc >> (32u - sh));
+		}
+#else
+		if (cnt)
+			L.rows[p * ROWW + (lane & 31)] = acc + pos;
+#endif
+	};
+	unsigned *stage = w.stage + img * w.SW;
+	// a plane's row to the staging buffer: the entry's own words (every entry starts on a word there: no word is
+	// shared, nothing is added atomically — a quarter of this kernel's time went into those two atomics per plane)
+	auto row_out = [&](int p, int refs, unsigned long long bit0) {
+		const int nw = (refs + 31) >> 5;
+		if (lane < nw)
+			stage[(bit0 >> 5) + lane] = L.rows[p * ROWW + lane];
+	};
+	if (NQ == 8) {
+		// Magnitudes below 256: the 16 of them as bytes, bit-transposed, are the lane's sixteen bits of every plane
+		// at once (byte p of A: coefficients 0..7, of B: 8..15).  A coefficient takes part in plane p's refinement
+		// pass if a higher plane has a bit of it: the OR of the bytes above.  The string is the plane's bits on those
+		// positions pushed together, a nibble per table look-up (PEXT4).
+		unsigned A0 = mag[0] | mag[1] << 8 | mag[2] << 16 | mag[3] << 24, A1 = mag[4] | mag[5] << 8 | mag[6] << 16 | mag[7] << 24;
+		unsigned B0 = mag[8] | mag[9] << 8 | mag[10] << 16 | mag[11] << 24, B1 = mag[12] | mag[13] << 8 | mag[14] << 16 | mag[15] << 24;
+		transpose8(A0, A1);
+		transpose8(B0, B1);
+		const unsigned SA1 = (A1 >> 8) | (A1 >> 16) | (A1 >> 24), SB1 = (B1 >> 8) | (B1 >> 16) | (B1 >> 24);
+		const unsigned SA0 = (A0 >> 8) | (A0 >> 16) | (A0 >> 24) | ((SA1 | A1) & 0xffu) * 0x01010101u;
+		const unsigned SB0 = (B0 >> 8) | (B0 >> 16) | (B0 >> 24) | ((SB1 | B1) & 0xffu) * 0x01010101u;
+		auto plane_string = [&](int p, unsigned Aw, unsigned SAw, unsigned Bw, unsigned SBw) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				return;   // uniform
+			const unsigned sh8 = 8u * ((unsigned)p & 3u);
+			const unsigned nA = (Aw >> sh8) & 0xffu, sA = (SAw >> sh8) & 0xffu, nB = (Bw >> sh8) & 0xffu, sB = (SBw >> sh8) & 0xffu;
+			const unsigned e0 = pext4[((sA & 15u) << 4) | (nA & 15u)], e1 = pext4[(sA & 0xf0u) | (nA >> 4)];
+			const unsigned e2 = pext4[((sB & 15u) << 4) | (nB & 15u)], e3 = pext4[(sB & 0xf0u) | (nB >> 4)];
+			const unsigned c0 = (unsigned)__builtin_popcount(sA & 15u), c1 = (unsigned)__builtin_popcount(sA);
+			const unsigned c2 = c1 + (unsigned)__builtin_popcount(sB & 15u), c3 = c1 + (unsigned)__builtin_popcount(sB);
+			deposit(p, e0 | e1 << c0 | e2 << c1 | e3 << c2, c3, L.tab[tab8(lane, p + 1)] & 0x3ffu, (unsigned)L.rb[p]);
+		};
+		for (int p = P - 2; p >= 4; --p)
+			plane_string(p, A1, SA1, B1, SB1);
+		for (int p = P - 2 < 3 ? P - 2 : 3; p >= 0; --p)
+			plane_string(p, A0, SA0, B0, SB0);
+		wave_sync();
+		PROF_MARK(7);   // strings deposited
+		for (int p = P - 2; p >= 0; --p) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				continue;
+			row_out(p, refs, L.rb[p]);
+		}
+	} else {
+		for (int p = P - 2; p >= 0; --p) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				continue;   // uniform
+			const unsigned thr = 2u << p;
+			unsigned acc = 0, cnt = 0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const bool isref = mag[i] >= thr;
+				acc |= (isref ? (mag[i] >> p) & 1u : 0u) << cnt;
+				cnt += isref ? 1u : 0u;
+			}
+			deposit(p, acc, cnt, L.tab[tab16(lane, p + 1)] & 0x3ffu, (unsigned)L.rb[p]);
+		}
+		wave_sync();
+		for (int p = P - 2; p >= 0; --p) {
+			const int refs = nvalid - (int)L.cum[p + 1];
+			if (refs <= 0 || L.ent[p] < 0)
+				continue;
+			row_out(p, refs, L.rb[p]);
+		}
+	}
+	wave_sync();   // the rows have been read: the token slots take their place
+	PROF_MARK(5);
 	// ---- pass B: every non-zero coefficient drops its zero count into its token slot (zeros into a dummy slot) ----
 	{
 		R_t R = 0;
@@ -1045,21 +1165,15 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 				const unsigned x = (unsigned)(R >> (4 * tm));
 				const unsigned lz_lo = x & 15u;
 				const unsigned lz_hi = t < NQ ? (x >> 4) & 15u : (unsigned)i;
-				const unsigned slot = mag[i] ? ent[i % NB8].y + lz_hi - lz_lo : (unsigned)(TILE + (lane & 7));
+				const unsigned slot = mag[i] ? ent[i % NB8].y + lz_hi - lz_lo : (unsigned)(ZS_DUMMY + (lane & 7));
 				L.zs[slot] = (unsigned short)(ent[i % NB8].x + lz_lo + ((sgn >> i) & 1u) * 0x1000u);
 				const int te = FULL || i < nv ? t : NQ;
 				R += te < NQ ? ONES << (4 * te) : (R_t)0;
 			}
 		}
 	}
-	// token base of every plane relative to its first slot (lane p holds plane p's)
-	if (lane < MAX_PLANES) {
-		L.gb[lane] = my_ent >= 0 ? my_tokbase - ((unsigned)nvalid - L.cum[lane + 1]) : ~0u;
-		L.ent[lane] = my_ent;
-		L.rb[lane] = my_rb;
-	}
 	wave_sync();
-
+	PROF_MARK(3);
 	// ---- tokens: run = zeros since the previous one of the same plane in this tile = a slot's zero count minus its
 	//      predecessor's; the first slot of a plane keeps its count.  Eight slots per lane at a time, two per instruction,
 	//      in place; then every plane's tokens — consecutive slots, consecutive in the stream — leave as they are ----
@@ -1071,129 +1185,63 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		if (lane < MAX_PLANES) {
 			const int p = lane;
 			const unsigned c0 = L.cum[p], c1 = L.cum[p + 1];
-			const unsigned ones = c1 - c0, slot0 = (unsigned)nvalid - c1;
+			const unsigned ones = c1 - c0, slot0 = L.slot0[p];
 			if (ones) {
 				first_slot = (int)slot0;
 				first_tok = L.zs[slot0];
 			}
-			if (L.ent[p] >= 0)
-				w.ent_tz[img * w.ES + L.ent[p]] = (unsigned short)(ones ? c0 - (L.zs[slot0 + ones - 1] & 0x3ffu) : c0);
+			if (my_ent >= 0)
+				w.ent_tz[img * w.ES + my_ent] = (unsigned short)(ones ? c0 - (L.zs[slot0 + ones - 1] & 0x3ffu) : c0);
 		}
-		const int nslots = nvalid - (int)L.cum[0];   // the tile's non-zero coefficients
+		const int nslots = (int)(first[0] + (cq(1) - cq(0)));   // where the lowest plane's tokens end
 		uint4 *zq = reinterpret_cast<uint4 *>(L.zs);
-		uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = a0;
-		unsigned before0 = 0, before1 = 0;
-		a0 = zq[lane];
-		before0 = lane ? (unsigned)L.zs[8 * lane - 1] << 16 : 0u;
-		if (nslots > 512) {   // uniform
-			a1 = zq[64 + lane];
-			before1 = (unsigned)L.zs[512 + 8 * lane - 1] << 16;
-		}
+		// (a block's first lane needs the slot before the block as it was: those are read before any block is rewritten;
+		// inside a block every lane has read before any lane writes — a wave's LDS operations execute in order)
+		const int nblk = (nslots + 511) >> 9;   // uniform, <= 3
+		unsigned before[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+			before[k] = k < nblk && 512 * k + 8 * lane > 0 && 512 * k + 8 * lane <= ZS_DUMMY ? (unsigned)L.zs[512 * k + 8 * lane - 1] << 16 : 0u;
 		wave_sync();
-		zq[lane] = make_uint4(slots_to_tokens(a0.x, before0), slots_to_tokens(a0.y, a0.x), slots_to_tokens(a0.z, a0.y), slots_to_tokens(a0.w, a0.z));
-		if (nslots > 512)
-			zq[64 + lane] = make_uint4(slots_to_tokens(a1.x, before1), slots_to_tokens(a1.y, a1.x), slots_to_tokens(a1.z, a1.y), slots_to_tokens(a1.w, a1.z));
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+			if (k < nblk && 64 * k + lane < ZS_DUMMY / 8) {
+				const uint4 a = zq[64 * k + lane];
+				zq[64 * k + lane] = make_uint4(slots_to_tokens(a.x, before[k]), slots_to_tokens(a.y, a.x), slots_to_tokens(a.z, a.y), slots_to_tokens(a.w, a.z));
+			}
 		wave_sync();
 		if (first_slot >= 0)
 			L.zs[first_slot] = (unsigned short)first_tok;
 		wave_sync();
+		PROF_MARK(4);   // tokens in place
 		unsigned short *tok16 = w.tok16 + img * w.TS;
+		// A plane's tokens to memory: slot and token sit alike modulo 8, so everything between the first and the last
+		// 16-byte boundary leaves as 16-byte pieces (2-byte stores, 64 to an instruction, were what this kernel
+		// waited for most); the up to seven tokens before and after go one by one, in one instruction.
+		auto plane_out = [&](unsigned tb, unsigned slot0, int ones) {
+			unsigned short *dst = tok16 + tb;
+			const unsigned short *src = L.zs + slot0;
+			const int head = min(ones, (int)((8u - (tb & 7u)) & 7u));
+			const int chunks = (ones - head) >> 3, tail0 = head + 8 * chunks;
+			const int e = lane < 8 ? lane : tail0 + lane - 8;   // lanes 0..7: the head, lanes 8..15: the tail
+			if (lane < 8 ? lane < head : (lane < 16 && e < ones))
+				dst[e] = src[e];
+			for (int c = lane; c < chunks; c += 64)
+				*reinterpret_cast<uint4 *>(dst + head + 8 * c) = *reinterpret_cast<const uint4 *>(src + head + 8 * c);
+		};
 		for (int p = P > 0 ? P - 1 : 0; p >= 0; --p) {
 			const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p]), c1 = (unsigned)__builtin_amdgcn_readfirstlane((int)L.cum[p + 1]);
 			const int ones = (int)(c1 - c0);
 			const unsigned gb = (unsigned)__builtin_amdgcn_readfirstlane((int)L.gb[p]);
 			if (ones <= 0 || gb == ~0u)
 				continue;   // uniform
-			const int slot0 = nvalid - (int)c1;
-			unsigned short *dst = tok16 + gb + (unsigned)slot0;
-			const unsigned short *src = L.zs + slot0;
-			for (int k = lane; k < ones; k += 64)
-				dst[k] = src[k];
+			plane_out(gb, (unsigned)__builtin_amdgcn_readfirstlane((int)L.slot0[p]), ones);
 		}
 	}
 
-	// ---- pass C: refinement bits (encode.c:84-93), per plane a <= 16-bit string per lane at rank (coefficients before) - Z[p+1] ----
-	wave_sync();
-	for (int i = lane; i < (MAX_PLANES - 1) * ROWW; i += 64)
-		L.rows[i] = 0u;
-	wave_sync();
-	// the lane's string of plane p at its place in the plane's row
-	auto deposit = [&](int p, unsigned acc, unsigned cnt) {
-		const unsigned zl = L.tab[NQ == 8 ? tab8(lane, p + 1) : tab16(lane, p + 1)] & 0x3ffu;   // Z[p+1] of the lanes before
-		const unsigned pos = (unsigned)(L.rb[p] & 31ull) + ((unsigned)vb - zl);
-		if (cnt) {
-			unsigned *row = L.rows + p * ROWW;
-			const unsigned sh = pos & 31u;
-			atomicOr(&row[pos >> 5], acc << sh);
-			if (sh + cnt > 32u)
-				atomicOr(&row[(pos >> 5) + 1], acc >> (32u - sh));
-		}
-	};
-	if (NQ == 8) {
-		// Magnitudes below 256: the 16 of them as bytes, bit-transposed, are the lane's sixteen bits of every plane
-		// at once (byte p of A: coefficients 0..7, of B: 8..15).  A coefficient takes part in plane p's refinement
-		// pass if a higher plane has a bit of it: the OR of the bytes above.  The string is the plane's bits on those
-		// positions pushed together, a nibble per table look-up (PEXT4).
-		unsigned A0 = mag[0] | mag[1] << 8 | mag[2] << 16 | mag[3] << 24, A1 = mag[4] | mag[5] << 8 | mag[6] << 16 | mag[7] << 24;
-		unsigned B0 = mag[8] | mag[9] << 8 | mag[10] << 16 | mag[11] << 24, B1 = mag[12] | mag[13] << 8 | mag[14] << 16 | mag[15] << 24;
-		transpose8(A0, A1);
-		transpose8(B0, B1);
-		const unsigned SA1 = (A1 >> 8) | (A1 >> 16) | (A1 >> 24), SB1 = (B1 >> 8) | (B1 >> 16) | (B1 >> 24);
-		const unsigned SA0 = (A0 >> 8) | (A0 >> 16) | (A0 >> 24) | ((SA1 | A1) & 0xffu) * 0x01010101u;
-		const unsigned SB0 = (B0 >> 8) | (B0 >> 16) | (B0 >> 24) | ((SB1 | B1) & 0xffu) * 0x01010101u;
-		auto plane_string = [&](int p, unsigned Aw, unsigned SAw, unsigned Bw, unsigned SBw) {
-			const int refs = nvalid - (int)L.cum[p + 1];
-			if (refs <= 0 || L.ent[p] < 0)
-				return;   // uniform
-			const unsigned sh8 = 8u * ((unsigned)p & 3u);
-			const unsigned nA = (Aw >> sh8) & 0xffu, sA = (SAw >> sh8) & 0xffu, nB = (Bw >> sh8) & 0xffu, sB = (SBw >> sh8) & 0xffu;
-			const unsigned e0 = pext4[((sA & 15u) << 4) | (nA & 15u)], e1 = pext4[(sA & 0xf0u) | (nA >> 4)];
-			const unsigned e2 = pext4[((sB & 15u) << 4) | (nB & 15u)], e3 = pext4[(sB & 0xf0u) | (nB >> 4)];
-			const unsigned c0 = (unsigned)__builtin_popcount(sA & 15u), c1 = (unsigned)__builtin_popcount(sA);
-			const unsigned c2 = c1 + (unsigned)__builtin_popcount(sB & 15u), c3 = c1 + (unsigned)__builtin_popcount(sB);
-			deposit(p, e0 | e1 << c0 | e2 << c1 | e3 << c2, c3);
-		};
-		for (int p = P - 2; p >= 4; --p)
-			plane_string(p, A1, SA1, B1, SB1);
-		for (int p = P - 2 < 3 ? P - 2 : 3; p >= 0; --p)
-			plane_string(p, A0, SA0, B0, SB0);
-	} else {
-		for (int p = P - 2; p >= 0; --p) {
-			const int refs = nvalid - (int)L.cum[p + 1];
-			if (refs <= 0 || L.ent[p] < 0)
-				continue;   // uniform
-			const unsigned thr = 2u << p;
-			unsigned acc = 0, cnt = 0;
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const bool isref = mag[i] >= thr;
-				acc |= (isref ? (mag[i] >> p) & 1u : 0u) << cnt;
-				cnt += isref ? 1u : 0u;
-			}
-			deposit(p, acc, cnt);
-		}
-	}
-	wave_sync();
-	{
-		unsigned *stage = w.stage + img * w.SW;
-		for (int p = P - 2; p >= 0; --p) {
-			const int refs = nvalid - (int)L.cum[p + 1];
-			if (refs <= 0 || L.ent[p] < 0)
-				continue;
-			const unsigned long long bit0 = L.rb[p];
-			const int nw = (int)(((unsigned)(bit0 & 31ull) + (unsigned)refs + 31u) >> 5);
-			if (lane < nw) {
-				const unsigned v = L.rows[p * ROWW + lane];
-				unsigned *dst = stage + (bit0 >> 5) + lane;
-				if (lane == 0 || lane == nw - 1) {
-					if (v)
-						atomicOr(dst, v);
-				} else {
-					*dst = v;
-				}
-			}
-		}
-	}
+	PROF_MARK(8);   // rows out
+#undef ZL
+#undef CT
 }
 
 // Two kernels: planes of up to 8 bit planes — every 8-bit picture — take the variant with 32-bit count registers,
@@ -1248,8 +1296,7 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 			const int k = k1 - 1;
 			const int e0 = w.seg_ebase[(long)img * (MAX_SEGS + 1) + k];
 			my_ent = e0 + j;
-			const unsigned *refscum = w.ent_refscum + img * (w.ES + 1);
-			my_rb = (w.seg_stage[(long)img * (MAX_SEGS + 1) + k] << 5) + (refscum[my_ent] - refscum[e0]);
+			my_rb = (unsigned long long)w.ent_refw[img * (w.ES + 1) + my_ent] << 5;   // (every entry's bits start on a word of the staging buffer)
 			my_tokbase = w.ent_tokbase[img * (w.ES + 1) + my_ent];
 		}
 	}
@@ -1265,7 +1312,7 @@ __device__ __forceinline__ void code_one(const PackGeom &g, const int *__restric
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_code(PackGeom g, const int *__restrict__ lin, Work w)
 {
 	__shared__ CodeLds lds[4];
 	__shared__ unsigned char pext4[256];
@@ -2164,64 +2211,129 @@ __global__ __launch_bounds__(256) void k_clear_stream(Work w, unsigned *out, lon
 }
 
 // --------------------------------------------------------------- k_refcopy ---
-// encode.c:84-93: a segment's raw refinement bits follow its first pass.  They wait in the staging
-// buffer, in coefficient order, each segment's block on a word boundary; their place in the stream
-// (seg_rawoff, noted by k_emit) is known now: a copy shifted by a constant number of bits per segment.
+// encode.c:84-93: a segment's raw refinement bits follow its first pass.  They wait in the staging buffer entry by
+// entry (tile by tile), every entry's bits from a word boundary on; their place in the stream (seg_rawoff, noted by
+// k_emit) is known now.  The segment's block is cut into windows of REF_WIN stream words; a workgroup gathers the
+// entries that reach into its window in LDS — each at its bit position, words added with LDS atomics — and writes
+// the window out as whole stream words; only the block's first and last word, which it shares with the tokens
+// around it, are added to the stream atomically.
+constexpr int REF_WIN = 2048;
+
 __global__ __launch_bounds__(256) void k_refcopy(Work w, unsigned *out, long out_words)
 {
 	const int img = blockIdx.y;
 	const int K = w.info[img].K;
-	const unsigned long long *sst = w.seg_stage + (long)img * (MAX_SEGS + 1);
-	const unsigned long long total = sst[K];
+	const int *eb = w.seg_ebase + (long)img * (MAX_SEGS + 1);
+	const unsigned *refscum = w.ent_refscum + img * (w.ES + 1), *refw = w.ent_refw + img * (w.ES + 1);
+	const unsigned short *erefs = w.ent_refs + img * w.ES;
 	const unsigned *stage = w.stage + img * w.SW;
 	unsigned *dst = out + img * out_words;
-	// every word looks its segment up (a binary search over the segments' first staging words, then the segment's
-	// size and place in the stream): from LDS, seven dependent reads from memory per word were most of this kernel
-	__shared__ unsigned long long l_sst[MAX_SEGS + 1], l_off[MAX_SEGS];
-	__shared__ unsigned l_refs[MAX_SEGS];
-	for (int k = threadIdx.x; k <= K; k += blockDim.x) {
-		l_sst[k] = sst[k];
-		if (k < K) {
-			l_refs[k] = w.seg_refs[(long)img * MAX_SEGS + k];
-			l_off[k] = w.seg_rawoff[(long)img * MAX_SEGS + k];
+	__shared__ unsigned win[REF_WIN + 2];      // [1 + word]: one guard word on either side
+	__shared__ unsigned wfirst[MAX_SEGS + 1];  // windows before segment k
+	__shared__ unsigned wsum[4];
+	// windows per segment, and their prefix (K <= 768: three segments per thread)
+	{
+		unsigned mine[3], sum = 0;
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int k = 3 * (int)threadIdx.x + u;
+			unsigned nwin = 0;
+			if (k < K) {
+				const unsigned n = w.seg_refs[(long)img * MAX_SEGS + k];
+				if (n) {
+					const unsigned long long D = w.seg_rawoff[(long)img * MAX_SEGS + k];
+					const unsigned long words = (unsigned long)(((D + n - 1) >> 5) - (D >> 5) + 1);
+					nwin = (unsigned)((words + REF_WIN - 1) / REF_WIN);
+				}
+			}
+			mine[u] = nwin;
+			sum += nwin;
 		}
+		unsigned total;
+		const unsigned pre = block_excl_scan(sum, wsum, total);
+		unsigned run = pre;
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int k = 3 * (int)threadIdx.x + u;
+			wfirst[k] = run;
+			run += mine[u];
+		}
+		if (threadIdx.x == blockDim.x - 1)
+			wfirst[MAX_SEGS] = run;
+		__syncthreads();
 	}
-	__syncthreads();
-	for (unsigned long long wi = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total;
-		wi += (unsigned long long)gridDim.x * blockDim.x) {
-		int lo = 0, hi = K - 1;   // the segment whose block holds staging word wi: largest k with sst[k] <= wi
+	const unsigned nwin_all = wfirst[K < MAX_SEGS ? K : MAX_SEGS];
+	for (unsigned vw = blockIdx.x; vw < nwin_all; vw += gridDim.x) {
+		// the window's segment: largest k with wfirst[k] <= vw among segments that have windows
+		int lo = 0, hi = K - 1;
 		while (lo < hi) {
 			const int mid = (lo + hi + 1) >> 1;
-			if (l_sst[mid] <= wi)
+			if (wfirst[mid] <= vw)
 				lo = mid;
 			else
 				hi = mid - 1;
 		}
 		const int k = lo;
-		const unsigned long i = (unsigned long)(wi - l_sst[k]);
-		const unsigned n = l_refs[k];
-		const unsigned long long D = l_off[k];
-		const int sh = (int)(D & 31);
-		const long d0 = (long)(D >> 5);
-		const unsigned long cw = ((unsigned long)n + 31) >> 5;            // staging words of the block
-		const unsigned long ndw = ((unsigned long)sh + n + 31) >> 5;      // stream words it touches
-		const unsigned cur = stage[wi];
-		const unsigned prev = i ? stage[wi - 1] : 0u;
-		const unsigned v = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
-		const long wd = d0 + (long)i;
-		if (wd < out_words) {
-			if (i == 0 || i == ndw - 1) {
+		const unsigned wi = vw - wfirst[k];
+		const unsigned n = w.seg_refs[(long)img * MAX_SEGS + k];
+		const unsigned long long D = w.seg_rawoff[(long)img * MAX_SEGS + k];
+		const long d0 = (long)(D >> 5), dl = (long)((D + n - 1) >> 5);
+		const long ws = d0 + (long)wi * REF_WIN;                          // the window's first stream word
+		const int nwords = (int)(dl - ws + 1 < REF_WIN ? dl - ws + 1 : REF_WIN);
+		// the window in the block's own bit coordinates (bit x of the block is stream bit D + x)
+		const long long x0 = ((long long)ws << 5) - (long long)D, x1 = x0 + 32ll * nwords;
+		for (int i = threadIdx.x; i < nwords + 2; i += blockDim.x)
+			win[i] = 0u;
+		__syncthreads();
+		// entries that reach into [x0, x1): from the last one that starts at or before x0 up to the first that starts at or after x1
+		const int e0 = eb[k], e1 = eb[k + 1];
+		const unsigned cbase = refscum[e0];
+		int a = e0, b = e1 - 1;
+		while (a < b) {   // largest entry with start <= max(x0, 0)
+			const int mid = (a + b + 1) >> 1;
+			if ((long long)(refscum[mid] - cbase) <= (x0 > 0 ? x0 : 0))
+				a = mid;
+			else
+				b = mid - 1;
+		}
+		for (int ea = a; ea < e1; ea += blockDim.x) {   // (uniform trip count: the stride leaves together, the entries' starts only grow)
+			const int e = ea + (int)threadIdx.x;
+			const long long c = e < e1 ? (long long)(refscum[e] - cbase) : x1;
+			if (__syncthreads_and(c >= x1))
+				break;
+			const unsigned r = e < e1 ? erefs[e] : 0u;
+			if (!r || c >= x1)
+				continue;
+			const unsigned *src = stage + refw[e];
+			const int nsrc = (int)((r + 31u) >> 5);
+			for (int jw = 0; jw < nsrc; ++jw) {
+				const long long o = c + 32ll * jw - x0;   // the source word's first bit, relative to the window
+				if (o <= -32 || o >= 32ll * nwords)
+					continue;
+				const unsigned v = src[jw];
+				const long long ob = o + 32;              // relative to the guard word
+				const int idx = (int)(ob >> 5), sh = (int)(ob & 31);
+				if (v) {
+					atomicOr(&win[idx], v << sh);
+					if (sh && idx + 1 < nwords + 2)
+						atomicOr(&win[idx + 1], v >> (32 - sh));
+				}
+			}
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < nwords; i += blockDim.x) {
+			const long wd = ws + i;
+			if (wd >= out_words)
+				continue;
+			const unsigned v = win[1 + i];
+			if (wd == d0 || wd == dl) {   // shared with the tokens before / after the block
 				if (v)
 					atomicOr(dst + wd, v);
 			} else {
 				dst[wd] = v;
 			}
 		}
-		if (i == cw - 1 && ndw > cw && wd + 1 < out_words) {   // the block's tail spills into one more stream word
-			const unsigned v2 = cur >> (32 - sh);
-			if (v2)
-				atomicOr(dst + wd + 1, v2);
-		}
+		__syncthreads();
 	}
 }
 
@@ -2335,8 +2447,8 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	w.NCS = (w.TS / SUB + FSUBS - 1) / FSUBS + 2;   // waves of the fast order pass (>= chunks of the exact one)
 	w.NGS = (w.NCS + GROUP - 1) / GROUP;
 	w.NCB = (w.ES + CARRY_BLOCK - 1) / CARRY_BLOCK;
-	// refinement bits: at most MAX_PLANES-1 per coefficient, every segment's block rounded up to a word
-	w.SW = (long)(((unsigned long long)C * (unsigned long long)(g.total - g.pixels[0]) * (MAX_PLANES - 1) + 31) / 32) + MAX_SEGS + 64;
+	// refinement bits: at most MAX_PLANES-1 per coefficient, every entry's bits rounded up to a word
+	w.SW = (long)(((unsigned long long)C * (unsigned long long)(g.total - g.pixels[0]) * (MAX_PLANES - 1) + 31) / 32) + w.ES + 64;
 	const int nplanes = n * C;
 
 	// carve scratch
@@ -2350,7 +2462,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		const size_t o_eb = take(sizeof(int) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_sr = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_ro = take(sizeof(unsigned long long) * (size_t)n * MAX_SEGS);
-		const size_t o_ss = take(sizeof(unsigned long long) * (size_t)n * (MAX_SEGS + 1));
 		const size_t o_bt = take(sizeof(unsigned) * (size_t)n * MAX_SEGS);
 		const size_t o_sx = take(sizeof(int) * (size_t)n * 48 * MAX_PLANES);
 		const size_t o_lv = take(sizeof(unsigned) * (size_t)n * 48);
@@ -2364,7 +2475,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.seg_ebase = (int *)(small + o_eb);
 		w.seg_refs = (unsigned *)(small + o_sr);
 		w.seg_rawoff = (unsigned long long *)(small + o_ro);
-		w.seg_stage = (unsigned long long *)(small + o_ss);
 		w.brk_tok = (unsigned *)(small + o_bt);
 		w.segidx = (int *)(small + o_sx);
 		w.live = (unsigned *)(small + o_lv);
@@ -2380,9 +2490,10 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		const size_t o_sg = take(sizeof(short) * (size_t)n * w.ES);
 		const size_t o_tb = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_rc = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
+		const size_t o_rw = take(sizeof(unsigned) * (size_t)n * (w.ES + 1));
 		const size_t o_ca = take(sizeof(RunMap) * (size_t)n * w.NCB);
 		const size_t o_ci = take(sizeof(unsigned) * (size_t)n * w.NCB);
-		const size_t o_ek = take(sizeof(unsigned) * 2 * (size_t)n * w.NCB);
+		const size_t o_ek = take(sizeof(unsigned) * 3 * (size_t)n * w.NCB);
 		char *ent = (char *)dwtx_scratch(ctx, SLOT_PK_ENT, off);
 		if (!ent)
 			return DWTX_ERR_NOMEM;
@@ -2393,6 +2504,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 		w.ent_seg = (unsigned short *)(ent + o_sg);
 		w.ent_tokbase = (unsigned *)(ent + o_tb);
 		w.ent_refscum = (unsigned *)(ent + o_rc);
+		w.ent_refw = (unsigned *)(ent + o_rw);
 		w.carry_agg = (RunMap *)(ent + o_ca);
 		w.carry_in = (unsigned *)(ent + o_ci);
 		w.ent_blk = (unsigned *)(ent + o_ek);
@@ -2440,7 +2552,6 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_entries_finish, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_entries_segs, dim3(n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_cut, dim3(n), dim3(ENT_BLOCK), 0, s, w, capacity, (int)(ctx->opt[DWTX_OPT_NO_CAPACITY_CUT] != 0));
-	hipLaunchKernelGGL(k_stage_zero, dim3((unsigned)w.NCB, n), dim3(ENT_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_code<false>, dim3(dwtx_cdiv(NT, 4), nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_code<true>, dim3(dwtx_cdiv(NT, 4) < 64 ? dwtx_cdiv(NT, 4) : 64, nplanes), dim3(256), 0, s, g, lin, w);
 	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
