@@ -10,7 +10,7 @@
 //               out for the stream stride but worked on only that far).
 //   k_peek + k_clear_bitmaps  the plane counts of every stream's preamble bound how much of
 //               its symbol bitmap can be used: only that much is cleared.
-//   k_spec/k_link_*/k_scan_*  speculative 128-bit chunk parse that lets the walker jump
+//   k_link_first/k_link_work/k_scan_*  speculative 128-bit chunk parse that lets the walker jump
 //               over stitched stretches of the stream (see below): one family of
 //               recorded paths, two (even / odd start) for a part of the batch whose
 //               walk gives up on a parity-locked stretch (k_part_reset).
@@ -59,7 +59,7 @@ constexpr int CH_LOG2 = 7;             // speculative-parse chunk: 128 stream bi
 constexpr int CH_BITS = 1 << CH_LOG2;
 constexpr int SCAN_BLOCK = 1024;       // chunks per scan workgroup
 constexpr int LINK_ROUNDS = 12;         // relaxation rounds: fewer leave more chunks unstitched, more let paths that ran through refinement blocks take over (both cost the walker; measured optimum 10-12)
-constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_spec)
+constexpr int FAM = 2;                 // speculative path families: start at bit 0 / bit 1 of a chunk (see k_link_first)
 
 struct UnpackGeom {
 	int levels, C, W, H;
@@ -128,7 +128,7 @@ struct DWork {
 	unsigned long long *count_base; // [nplanes][16] k_rank -> k_count: 1 + 2 * symbol base of the (plane, level)'s segment at the current bit plane, 0 = none
 	long BW;                        // bitmap words per image
 	int NT;
-	// speculative chunk parse (see k_spec): per 128-bit chunk of every stream
+	// speculative chunk parse (see k_link_first): per 128-bit chunk of every stream
 	unsigned short *exitX;          // [n*FAM][NCH] rel | order<<8: state in which the chunk's recorded path leaves it; 0xffff dead
 	unsigned short *entryE;         // [n*FAM][NCH] state in which that recorded path entered (valid if == exitX[chunk-1])
 	unsigned long long *cs;         // [n][NCH+1] exclusive prefix of symbols (run+1) along the arriving paths
@@ -154,7 +154,7 @@ struct DWork {
 	SegResult *segres;              // [n][MAX_SEGS] indexed walk: where each segment's own wave ended up
 	int *idx_nsegs;                 // [n] segments in idx (indexed walk: 0 = no usable index for this image)
 	unsigned *seg_slot;             // [n][MAX_SEGS + 1] indexed walk: first hop record of every segment's private stretch
-	int fam;                        // families in use this pass: 1 (the usual case) or FAM (see k_spec); the tables keep FAM rows per image either way
+	int fam;                        // families in use this pass: 1 (the usual case) or FAM (see k_link_first); the tables keep FAM rows per image either way
 };
 
 // grid row -> virtual stream (image * FAM + family) when only w.fam of the FAM families run
@@ -326,7 +326,7 @@ struct BitmapWriter {
 // is a pure function of it: f(b,o) = (b + 2z + o + 2, max(o+z-2, 0)), z = zeros
 // before the next one bit.  Paths that ever share a state coincide from there
 // on, and in practice they do merge within a few tokens.  So every 128-bit chunk
-// is parsed from (chunk start, order 0) [path P, k_spec] and again from the
+// is parsed from (chunk start, order 0) [path P, k_link_first] and again from the
 // state in which P of the previous chunk arrives [path Q, k_link].  Where Q
 // leaves the chunk in the same state as P, the stream is "stitched": a walker
 // that enters a chunk in the state P of the previous chunk left it in follows Q
@@ -502,26 +502,6 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 // kernels run a capped grid whose workgroups stride over the virtual blocks of 256 chunks that hold data.
 constexpr int CHUNK_GRID = 2048;
 
-__global__ __launch_bounds__(256) void k_spec(DWork w, const unsigned char *streams, long stream_stride)
-{
-	const int vs = vstream(w, blockIdx.y), img = vs / FAM;   // virtual stream = (image, family)
-	const long nch = w.nch[img];
-	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
-		if (chunk >= nch)
-			continue;
-		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
-		// At order 0 every token has even length (2z + o + 2), so two parses that start an odd
-		// number of bits apart cannot meet while the order stays 0: seed both parities.
-		// The warm-up only has to run long enough for the speculative path to fall in with the true one: starting in
-		// the middle of the chunk halves this kernel and costs the relaxation rounds a little (starting at three
-		// quarters costs them more than it saves); the walker sees the same stitched runs.
-		int off = (w.fam == 1 ? 0 : CH_BITS / 2) + vs % FAM, o = 0;
-		const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
-		const unsigned short out = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
-		w.exitX[vs * w.NCH + chunk] = out;
-	}
-}
-
 // One refinement round: parse chunk i from the state in which the previous
 // round's path left chunk i-1.  After r rounds the entry state of a chunk is what
 // a parse started r chunks earlier (at order 0) arrives with, so it agrees with
@@ -583,16 +563,61 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 	}
 }
 
-// round 1: every chunk; a chunk whose exit moved hands its successor to the work list
-__global__ __launch_bounds__(256) void k_link_all(DWork w, const unsigned char *streams, long stream_stride)
+// Speculation and the first relaxation round in one kernel: a thread parses its chunk from the speculative start —
+// the chunk's first bit at order 0; with two families its middle plus the family's parity: at order 0 every token
+// has even length (2z + o + 2), so two parses that start an odd number of bits apart cannot meet while the order
+// stays 0 — hands the exit to its right-hand neighbour through LDS, and parses the chunk again from the exit its
+// left-hand neighbour speculated, recording counts.  A chunk whose linked exit differs from its speculated one
+// hands its successor to the work list (round 2).  The chunk's words are loaded once and no table travels through
+// memory between the two parses (rounds 1-2 used to be k_spec + k_link_all: 1.93 -> 1.77 ms per 64 frames).
+// A workgroup's first thread only speculates: its chunk is linked by the workgroup before (strides of 255 chunks).
+__global__ __launch_bounds__(256) void k_link_first(DWork w, const unsigned char *streams, long stream_stride)
 {
-	const int vs = vstream(w, blockIdx.y);
-	const long nch = w.nch[vs / FAM];
-	for (long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x; chunk - threadIdx.x < nch; chunk += (long)gridDim.x * blockDim.x) {
+	__shared__ unsigned short sx[256];
+	const int vs = vstream(w, blockIdx.y), img = vs / FAM;
+	const long nch = w.nch[img];
+	const int start = (w.fam == 1 ? 0 : CH_BITS / 2) + vs % FAM;
+	for (long base = (long)blockIdx.x * 255; base < nch; base += (long)gridDim.x * 255) {   // uniform
+		const long chunk = base + threadIdx.x;
+		ChunkWin c = { 0ull, 0ull, 0ull };
+		unsigned short spec = 0xffff;
+		if (chunk < nch) {
+			c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
+			int off = start, o = 0;
+			const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
+			spec = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
+		}
+		sx[threadIdx.x] = spec;
+		__syncthreads();
 		bool moved = false;
-		if (chunk >= 1 && chunk < nch)
-			moved = link_parse(w, streams, stream_stride, vs, chunk);
-		link_push(w, vs, chunk + 1, moved, w.todo[1], w.todo_count + 2 * w.todo_round);
+		if (chunk < nch) {
+			if (chunk == 0) {
+				w.exitX[vs * w.NCH] = spec;
+			} else if (threadIdx.x) {
+				const unsigned short in = sx[threadIdx.x - 1];
+				const long ci = vs * (w.NCH + 1) + chunk;
+				unsigned long long sym = 0;
+				unsigned tok = 0;
+				unsigned short out = 0xffff;
+				if (in != 0xffff) {
+					int off = in & 0xff, o = in >> 8;
+					const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
+						++tok;
+						sym += (unsigned long long)run + 1ull;
+						return true;
+					});
+					if (alive)
+						out = (unsigned short)((off - CH_BITS) | (o << 8));
+				}
+				w.entryE[vs * w.NCH + chunk] = in;
+				w.cs[ci] = sym;
+				w.ct[ci] = tok;
+				w.exitX[vs * w.NCH + chunk] = out;
+				moved = out != spec && chunk + 1 < nch;   // the successor was linked from `spec`
+			}
+		}
+		link_push(w, vs, chunk + 1, moved && threadIdx.x != 0, w.todo[1], w.todo_count + 2 * w.todo_round);
+		__syncthreads();   // sx is reused by the next stride
 	}
 }
 
@@ -1251,7 +1276,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	unsigned long long symtotal = SEG ? idx[seg_k].sym_base : 0ull;
 	int nsegs = seg_k, level = -1;
 
-	// stitched-chunk tables of this stream (k_spec / k_link / k_scan_* / k_breaks)
+	// stitched-chunk tables of this stream (k_link_* / k_scan_*)
 	const unsigned short *exitX0 = w.exitX + (long)img * FAM * w.NCH;
 	const unsigned long long *CS0 = w.cs + (long)img * FAM * (w.NCH + 1);
 	const unsigned *CT0 = w.ct + (long)img * FAM * (w.NCH + 1), *CG0 = w.cg + (long)img * FAM * (w.NCH + 1);
@@ -1267,7 +1292,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 #define WALK_MARK()
 #define WALK_ADD(acc)
 #endif
-	// With one family the walk can meet a stretch that the recorded paths do not follow at all (k_spec): it gives
+	// With one family the walk can meet a stretch that the recorded paths do not follow at all (k_link_first): it gives
 	// up when the chunks it parses by hand pile up, and the host repeats the part with both families.
 	unsigned scans = 0, streak = 0;
 	bool giveup = false;
@@ -2277,8 +2302,9 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		const unsigned cblocks = (unsigned)((w.NCH + 1 + 255) / 256);
 		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * h.fam);
-		hipLaunchKernelGGL(k_spec, cg, dim3(256), 0, st, h, str, (long)stream_stride);
-		hipLaunchKernelGGL(k_link_all, cg, dim3(256), 0, st, h, str, (long)stream_stride);   // round 1, fills the list of chunks to redo
+		const unsigned fblocks = (unsigned)((w.NCH + 1 + 254) / 255);
+		hipLaunchKernelGGL(k_link_first, dim3(fblocks < CHUNK_GRID ? fblocks : CHUNK_GRID, cnt * h.fam), dim3(256), 0, st, h, str,
+			(long)stream_stride);   // speculation and round 1 in one, fills the list of chunks to redo
 		int cur = 1;
 		for (int r = 2; r <= LINK_ROUNDS; ++r) {   // the lists shrink: fewer workgroups per shard after the first rounds
 			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * (r <= 3 ? 4 : 1), cnt * h.fam), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
@@ -2291,7 +2317,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		DWTX_LAUNCH_CHECK();
 		return DWTX_OK;
 	};
-	// One family of recorded paths is enough for almost every stream (k_spec); DWTX_TWO_FAMILIES starts with both
+	// One family of recorded paths is enough for almost every stream (k_link_first); DWTX_TWO_FAMILIES starts with both
 	// (a test hook: it is the path a walk that gave up falls back to).
 	// One or two images leave most of the chip idle anyway: both families then, for the shorter walk.
 	const int fam0 = n <= 2 || ctx->opt[DWTX_OPT_TWO_FAMILIES] ? FAM : 1;
