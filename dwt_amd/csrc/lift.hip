@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int WAVES = 4;          // waves per block, stacked along y
-constexpr int MAX_ROWS_PER_WAVE = 32; // output row pairs per wave strip (fewer on small levels, to keep the chip full)
+constexpr int MAX_ROWS_PER_WAVE = 64; // output row pairs per wave strip (fewer on small levels, to keep the chip full); 64 instead of 32: half the halo rows, forward 37 -> 34.5 us per 4096x4096 plane
 
 struct LevelArgs {
 	const int *src;  long src_ps;  int spitch;  // forward: input w*h      | inverse: LL (w2*h2)
