@@ -48,24 +48,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef DWTX_PROF_SECTIONS   // experiment builds: cycles per section of k_code, summed over waves (tools only, never shipped)
-__device__ unsigned long long g_prof[16];
-extern "C" void dwtx_debug_prof(unsigned long long *out, int reset)
-{
-	if (out)
-		(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
-	if (reset) {
-		unsigned long long z[16] = { 0 };
-		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
-	}
-}
-#define PROF_MARK(k) do { const unsigned long long t_now_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_prof[k], t_now_ - t_prof_); t_prof_ = t_now_; } while (0)
-#define PROF_BEGIN() unsigned long long t_prof_ = __builtin_readcyclecounter()
-#else
-#define PROF_MARK(k)
-#define PROF_BEGIN()
-#endif
-
 namespace {
 
 constexpr int TILE = 1024;
@@ -954,7 +936,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 {
 	// Planes at or above the tile's own bit-plane count hold nothing but zeros here: all per-class work stops at P
 	const int P = Pc < tile_top ? Pc : tile_top;
-	PROF_BEGIN();
 	typedef typename Nib<NQ>::T R_t;
 	constexpr R_t ONES = Nib<NQ>::ONES, M0F = Nib<NQ>::M0F;
 	constexpr int NB = NQ / 4;   // dwords of 16-bit fields per parity
@@ -998,7 +979,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		E[b] = ei - e0;   // exclusive: the lanes before this one
 		O[b] = oi - o0;
 	}
-	PROF_MARK(1);   // pass A + scans
 	// Z over the lanes before me / the whole tile, q a compile-time constant after unrolling
 #define ZL(q) ((((q) & 1 ? O[((q) >> 2) % NB] : E[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
 #define CT(q) ((((q) & 1 ? cO[((q) >> 2) % NB] : cE[((q) >> 2) % NB]) >> (16 * (((q) >> 1) & 1))) & 0xffffu)
@@ -1034,7 +1014,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 			L.slot0[q] = (unsigned short)(q < NQ ? first[q < NQ ? q : 0] : 0u);
 	}
 	wave_sync();
-	PROF_MARK(2);   // table
 
 	// per-plane facts of the tile for the plane loops below (lane p holds plane p's)
 	if (lane < MAX_PLANES) {
@@ -1054,11 +1033,9 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 	for (int i = lane; i < (NQ - 1) * ROWW; i += 64)
 		L.rows[i] = 0u;
 	wave_sync();
-	PROF_MARK(6);   // rows zeroed
 	// the lane's string of plane p at its place in the plane's row: zl = Z[p+1] of the lanes before, bit0 = where the entry's bits start
 	auto deposit = [&](int p, unsigned acc, unsigned cnt, unsigned zl, unsigned bit0) {
 		const unsigned pos = (bit0 & 31u) + ((unsigned)vb - zl);
-#ifndef EXP_NODEPOSIT
 		if (cnt) {
 			unsigned *row = L.rows + p * ROWW;
 			const unsigned sh = pos & 31u;
@@ -1066,10 +1043,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 			if (sh + cnt > 32u)
 				atomicOr(&row[(pos >> 5) + 1], acc >> (32u - sh));
 		}
-#else
-		if (cnt)
-			L.rows[p * ROWW + (lane & 31)] = acc + pos;
-#endif
 	};
 	unsigned *stage = w.stage + img * w.SW;
 	// a plane's row to the staging buffer: the entry's own words (every entry starts on a word there: no word is
@@ -1108,7 +1081,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		for (int p = P - 2 < 3 ? P - 2 : 3; p >= 0; --p)
 			plane_string(p, A0, SA0, B0, SB0);
 		wave_sync();
-		PROF_MARK(7);   // strings deposited
 		for (int p = P - 2; p >= 0; --p) {
 			const int refs = nvalid - (int)L.cum[p + 1];
 			if (refs <= 0 || L.ent[p] < 0)
@@ -1139,7 +1111,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		}
 	}
 	wave_sync();   // the rows have been read: the token slots take their place
-	PROF_MARK(5);
 	// ---- pass B: every non-zero coefficient drops its zero count into its token slot (zeros into a dummy slot) ----
 	{
 		R_t R = 0;
@@ -1173,7 +1144,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		}
 	}
 	wave_sync();
-	PROF_MARK(3);
 	// ---- tokens: run = zeros since the previous one of the same plane in this tile = a slot's zero count minus its
 	//      predecessor's; the first slot of a plane keeps its count.  Eight slots per lane at a time, two per instruction,
 	//      in place; then every plane's tokens — consecutive slots, consecutive in the stream — leave as they are ----
@@ -1213,7 +1183,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		if (first_slot >= 0)
 			L.zs[first_slot] = (unsigned short)first_tok;
 		wave_sync();
-		PROF_MARK(4);   // tokens in place
 		unsigned short *tok16 = w.tok16 + img * w.TS;
 		// A plane's tokens to memory: slot and token sit alike modulo 8, so everything between the first and the last
 		// 16-byte boundary leaves as 16-byte pieces (2-byte stores, 64 to an instruction, were what this kernel
@@ -1239,7 +1208,6 @@ __device__ __forceinline__ void code_tile(CodeLds &L, const unsigned char *pext4
 		}
 	}
 
-	PROF_MARK(8);   // rows out
 #undef ZL
 #undef CT
 }
