@@ -448,7 +448,7 @@ def main():
     # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE in separate passes),
     # collected in a separate profiling run (profiles/): the counters cannot be read from inside this process
     traffic = traffic_detail = None
-    for tname in ("r02_lift_traffic_pmc.json", "r01_lift_traffic_pmc.json"):
+    for tname in ("r03_lift_traffic_pmc.json", "r02_lift_traffic_pmc.json", "r01_lift_traffic_pmc.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -460,6 +460,10 @@ def main():
             for key in ("per_kernel", "planes"):
                 if key in tj:
                     traffic_detail[key] = tj[key]
+            # the finest level's u8 kernels as the codec runs them (pixels in, int32 subbands out and back): 5 B per sample
+            u8path = os.path.join(ROOT, "profiles", "r03_lift8_traffic_pmc.json")
+            if os.path.exists(u8path):
+                traffic_detail["u8_finest_level_kernels"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r03_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")
             break
 
     result = None

@@ -65,7 +65,7 @@ for case in range(cases):
         assert cut[i] == w2, ("capacity bytes", case, i, W, H, Cn, cap)
         assert (cstats[i].meta_bits, cstats[i].root_bits, cstats[i].total_bits) == (s2.meta_bits, s2.root_bits, s2.total_bits), ("capacity stats", case, i, cap)
     px = int(rng.integers(0, 3 * W * H))
-    for blobs, cap_px in ((cut, -1), (streams, px), ([s[: max(1, len(s) // 3)] for s in streams], -1)):
+    for blobs, cap_px in ((cut, -1), (streams, px), ([s[: max(6, len(s) // 3)] for s in streams], -1)):   # (6: a batch's geometry is its first stream's header)
         got = ctx.decode(list(blobs), cap_px)
         for i, b in enumerate(blobs):
             ref = orc.decode(b, cap_px)

@@ -28,7 +28,7 @@ out = {"what": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES over tools
 for side, names in (("encode", ENC), ("decode", DEC)):
     valu = salu = 0.0
     for n, c in tot.items():
-        if n.startswith(names):
+        if n.startswith(names) and not n.startswith("k_planes_"):   # (k_plan is the coder's, k_planes_from_pixels the tool's preparation)
             v, s_, wv = c["SQ_INSTS_VALU"] / reps, c["SQ_INSTS_SALU"] / reps, c["SQ_WAVES"] / reps
             valu += v
             salu += s_

@@ -1,0 +1,40 @@
+#!/bin/bash
+# HBM traffic of the finest-level kernels the pipelines actually run on 8-bit gray pixels (k_fwd_level_w<unsigned char, true> with
+# the fused histogram, k_inv_level_w<unsigned char>), per sample: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over
+# tools/time_codec.py 4096 4096 1 16, calibrated like tools/pmc_lift.sh on plain copies of the same access widths
+# (forward: 4-byte loads, 8-byte stores; inverse: 8-byte loads, 4-byte stores).   tools/pmc_lift8.sh > profiles/rNN_lift8_traffic_pmc.json
+export DWTX_ONE_STREAM=1
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+	rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c -- python3 $GRAFT_REPO_ROOT/tools/time_codec.py 4096 4096 1 16 > /dev/null 2>&1
+	rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > /dev/null 2>&1
+done
+cd $GRAFT_REPO_ROOT && python3 - <<'PY'
+import csv, glob, json, collections
+def rows(d, counter):
+    f = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            yield r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], float(r["Counter_Value"])
+cal = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for n, v in rows(f"pmc8cal_{c}", c):
+        acc[n].append(v)
+    for n, v in acc.items():
+        if n in ("copy16", "copy8", "copy4"):
+            cal[(c, n)] = (1 << 20) / (sum(v) / len(v))
+width = {"k_fwd_level_w<unsigned char, true>": (4, 8), "k_inv_level_w<unsigned char>": (8, 4)}
+out = {"what": "HBM traffic per sample of the finest-level kernels of dwtx_encode_device / dwtx_decode_device on 4096x4096 8-bit gray frames "
+               "(16 frames per call; forward: 1 B of pixels in, the four subbands out as int32 = 4 B; inverse: the reverse)",
+       "calibration_true_over_reported": {f"{c}/{n}": round(v, 3) for (c, n), v in cal.items()}, "per_kernel": {}}
+for kn, (lw, sw) in width.items():
+    f = [v for n, v in rows("pmc8_FETCH_SIZE", "FETCH_SIZE") if n == kn]
+    wv = [v for n, v in rows("pmc8_WRITE_SIZE", "WRITE_SIZE") if n == kn]
+    samples = 16 * 4096 * 4096
+    rd = sum(f) / len(f) * cal[("FETCH_SIZE", f"copy{lw}")] * 1024 / samples
+    wr = sum(wv) / len(wv) * cal[("WRITE_SIZE", f"copy{sw}")] * 1024 / samples
+    out["per_kernel"][kn] = {"launches": len(f), "read_bytes_per_sample": round(rd, 3), "write_bytes_per_sample": round(wr, 3),
+                             "algorithmic_bytes_per_sample": 5.0}
+print(json.dumps(out, indent=1))
+PY
