@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { SLOT_CD_A = 16, SLOT_CD_B, SLOT_CD_INFO, SLOT_CD_IO, SLOT_CD_IO2, SLOT_CD_LENS };
+enum { SLOT_CD_A = 16, SLOT_CD_B, SLOT_CD_INFO, SLOT_CD_IO, SLOT_CD_IO2, SLOT_CD_LENS, SLOT_CD_F16 };
 
 extern "C" size_t dwtx_encode_bound(int W, int H, int C)
 {
@@ -35,8 +35,20 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 	unsigned hist_levels = 0;
 	if ((rc = dwtx_hist_begin(ctx, W, H, C, n, &sink)))
 		return rc;
-	if (dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C)) {
-		if ((rc = dwtx_fwd_pixels8_hist(ctx, b, dev_pix, W, H, C, n, &sink, &hist_levels)))   // encode.c:155-159 in one pass
+	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
+	const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
+	// The finest ring — three quarters of all coefficients — as 16-bit values in planes of its own when the transform
+	// starts from 8-bit pixels (no coefficient of that ring can leave 11 bits then) and the coder reads its squares in
+	// place: the transform writes, and the coder reads, half the bytes for it.
+	int16_t *fine16 = nullptr;
+	const bool from_pixels = dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C);
+	if (from_pixels && sq && !ctx->opt[DWTX_OPT_NO_FINE16] && dwtx_fine16_ok(W, H, sq)) {
+		fine16 = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
+		if (!fine16)
+			return DWTX_ERR_NOMEM;
+	}
+	if (from_pixels) {
+		if ((rc = dwtx_fwd_pixels8_hist(ctx, b, dev_pix, W, H, C, n, &sink, &hist_levels, fine16)))   // encode.c:155-159 in one pass
 			return rc;
 	} else {
 		if ((rc = dwtx_planes_from_pixels(ctx, a, dev_pix, W, H, C, n)))       // encode.c:155-156
@@ -44,13 +56,11 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 		if ((rc = dwtx_transformation_fwd_hist(ctx, b, a, W, H, n * C, &sink, &hist_levels)))   // encode.c:159
 			return rc;
 	}
-	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
-	const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
-	if ((rc = dwtx_linearization_ex(ctx, a, b, W, H, n * C, sq)))
+	if ((rc = dwtx_linearization_ex(ctx, a, b, W, H, n * C, sq, fine16)))
 		return rc;
 	if (lifted)
 		DWTX_HIP(hipEventRecord(lifted, ctx->stream));
-	return dwtx_encode_planes_ex(ctx, a, b, sq, hist_levels, W, H, C, n, capacity, dev_out, out_stride, dev_info);   // encode.c:163-221
+	return dwtx_encode_planes_ex(ctx, a, b, sq, hist_levels, W, H, C, n, capacity, dev_out, out_stride, dev_info, fine16);   // encode.c:163-221
 }
 
 // pixels (device) -> streams (device); async on the context's stream.
@@ -115,6 +125,16 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 	if (!a || !b)
 		return DWTX_ERR_NOMEM;
 	const size_t plane_ints = (size_t)W * H;
+	// 16-bit planes for the finest ring of whole pictures (see encode_part; the decoder checks the streams' plane counts)
+	int16_t *fine16 = nullptr;
+	{
+		const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
+		if (sq && !ctx->opt[DWTX_OPT_NO_FINE16] && dwtx_fine16_ok(W, H, sq) && dwtx_gray8_ok(W, H, dev_pix, pix_stride)) {
+			fine16 = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
+			if (!fine16)
+				return DWTX_ERR_NOMEM;
+		}
+	}
 	// scratch both parts of the batch will ask for, sized once for the larger request
 	{
 		const size_t part_planes = (size_t)(n < 4 ? n : n - n / 2) * C;
@@ -147,11 +167,13 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		int *lin = a + plane_ints * C * first;
 		int *pyr = b + plane_ints * C * first;
 		int *img = a + plane_ints * C * first;   // lin is dead once reconstructed
+		int16_t *f16 = (fused & DWTX_FUSED_FINE16) ? fine16 + plane_ints * C * first : nullptr;   // the decoder put the part's finest ring there
+		fused &= ~DWTX_FUSED_FINE16;
 		int r;
-		if ((r = dwtx_reconstruction_ex(ctx, pyr, lin, miss, lo, W, H, C, count, fused)))    // decode.c:257 (the rest of it)
+		if ((r = dwtx_reconstruction_ex(ctx, pyr, lin, miss, lo, W, H, C, count, fused, f16)))    // decode.c:257 (the rest of it)
 			return r;
 		if (dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
-			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count);   // decode.c:258-264
+			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count, f16);   // decode.c:258-264
 		if ((r = dwtx_transformation_inv(ctx, img, pyr, ow, oh, count * C)))                 // decode.c:258
 			return r;
 		if (count == 1 || (size_t)ow * oh * C == pix_stride)
@@ -179,7 +201,7 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 	};
 	using Part = decltype(part);
 	return dwtx_decode_planes_ex(ctx, a, b, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info,
-		[](void *user, int first, int count, unsigned fused) { return (*(Part *)user)(first, count, fused); }, &part);
+		[](void *user, int first, int count, unsigned fused) { return (*(Part *)user)(first, count, fused); }, &part, fine16);
 }
 
 // ---- host-buffer wrappers (what the CLIs call) ---------------------------------

@@ -183,5 +183,62 @@ __device__ __forceinline__ void store_square16(int *__restrict__ plane_pyr, int 
 	sq_wave_sync();
 }
 
+// The same for a plane kept as 16-bit coefficients (the finest ring of an 8-bit source, lift.hip): 64-byte rows,
+// widened on the way into LDS / narrowed on the way out, so that the staged square is the one above.
+__device__ __forceinline__ void load_square16(const short *__restrict__ plane_pyr, int ppitch, int n, int blk, int lane,
+	unsigned *lds, int (&val)[16])
+{
+	const SquareMap m = square_map(n, (unsigned)blk);
+	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		const int row = it * 16 + (lane >> 2), c8 = (lane & 3) * 8;
+		const uint4 v = *reinterpret_cast<const uint4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c8);
+		const unsigned u[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int c4 = c8 + 4 * h;
+			const int4 w = make_int4((int)(short)(u[2 * h] & 0xffffu), (int)u[2 * h] >> 16, (int)(short)(u[2 * h + 1] & 0xffffu), (int)u[2 * h + 1] >> 16);
+			*reinterpret_cast<int4 *>(lds + ((row << 5) | (c4 ^ ((row & 7) << 2)))) = w;
+		}
+	}
+	unsigned pos[16];
+	square_positions16(m, lane, pos);
+	sq_wave_sync();
+	const char *base = reinterpret_cast<const char *>(lds);
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+		val[k] = *reinterpret_cast<const int *>(base + pos[k]);
+	sq_wave_sync();
+}
+
+__device__ __forceinline__ void store_square16(short *__restrict__ plane_pyr, int ppitch, int n, int blk, int lane, unsigned *lds,
+	const int (&val)[16])
+{
+	const SquareMap m = square_map(n, (unsigned)blk);
+	const unsigned X0 = m.mx & ~31u, Y0 = m.my & ~31u;
+	unsigned pos[16];
+	square_positions16(m, lane, pos);
+	char *base = reinterpret_cast<char *>(lds);
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+		*reinterpret_cast<int *>(base + pos[k]) = val[k];
+	sq_wave_sync();
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		const int row = it * 16 + (lane >> 2), c8 = (lane & 3) * 8;
+		unsigned u[4];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int c4 = c8 + 4 * h;
+			const int4 w = *reinterpret_cast<const int4 *>(lds + ((row << 5) | (c4 ^ ((row & 7) << 2))));
+			u[2 * h] = ((unsigned)w.x & 0xffffu) | ((unsigned)w.y << 16);
+			u[2 * h + 1] = ((unsigned)w.z & 0xffffu) | ((unsigned)w.w << 16);
+		}
+		*reinterpret_cast<uint4 *>(plane_pyr + (long)(Y0 + row) * ppitch + X0 + c8) = make_uint4(u[0], u[1], u[2], u[3]);
+	}
+	sq_wave_sync();
+}
+
 } // namespace
 

@@ -35,6 +35,7 @@ struct LevelArgs {
 	int rpw;          // output row pairs per wave strip
 	const uint8_t *src8;   // forward, finest level of a gray image: 8-bit pixels instead of src (pnm.h:69-74 widening fused)
 	uint8_t *dst8;         // inverse, finest level of a gray image: clamped 8-bit pixels instead of ll (pnm.h:108 fused)
+	short *det16;          // or null: this level's detail bands live here as 16-bit values (same positions, pitch and plane stride as det)
 };
 
 // ---------------------------------------------------------------- forward ---
@@ -501,6 +502,11 @@ __device__ __forceinline__ void st2(int *p, I2 v)
 	*reinterpret_cast<int2 *>(p) = make_int2(v.a, v.b);
 }
 
+__device__ __forceinline__ void st2(short *p, I2 v)
+{
+	*reinterpret_cast<unsigned *>(p) = ((unsigned)v.a & 0xffffu) | ((unsigned)v.b << 16);
+}
+
 // first sample of the plane's source and the channel a launch extracts (RGB only)
 __device__ __forceinline__ const int *fwd_base(SrcTag<int>, const LevelArgs &a, int plane, int &ch)
 {
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	const typename SrcElem<SrcT>::type *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
 	int *ll = a.ll + plane * a.ll_ps;
 	int *det = a.det + plane * a.det_ps;
+	short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;   // (uniform)
 
 	int jj = j0 > 0 ? j0 - 1 : 0;
 	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
@@ -625,10 +632,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 				sh = i2_upd(h0, jj ? ph : dh, dh);
 			}
 			st2(ll + (long)jj * a.llpitch + 2 * q, sl);
-			st2(det + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
-			if (odd_in) {
-				st2(det + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
-				st2(det + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+			if (det16) {
+				st2(det16 + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
+				if (odd_in) {
+					st2(det16 + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
+					st2(det16 + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+				}
+			} else {
+				st2(det + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
+				if (odd_in) {
+					st2(det + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
+					st2(det + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+				}
 			}
 		}
 		if (HIST && jj >= j0) {
@@ -670,16 +685,32 @@ struct InvRaw {
 	int2 sl, sh, dl, dh;   // LL | HL | LH | HH samples of one row pair
 };
 
-__device__ __forceinline__ InvRaw inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, int qd, bool valid)
+__device__ __forceinline__ int2 ld2(const int *p) { return *reinterpret_cast<const int2 *>(p); }
+__device__ __forceinline__ int2 ld2(const short *p)
+{
+	const unsigned u = *reinterpret_cast<const unsigned *>(p);
+	return make_int2((int)(short)(u & 0xffffu), (int)u >> 16);
+}
+
+// det16 (uniform): the detail bands as 16-bit values, plane `det16` instead of `det`
+__device__ __forceinline__ InvRaw inv_load_w(const LevelArgs &a, const int *llp, const int *det, const short *det16, int j, int qd, bool valid)
 {
 	InvRaw r;
 	r.sl = r.sh = r.dl = r.dh = make_int2(0, 0);
 	if (valid && j < a.h2) {
-		r.sl = *reinterpret_cast<const int2 *>(llp + (long)j * a.spitch + 2 * qd);
-		r.sh = *reinterpret_cast<const int2 *>(det + (long)j * a.dpitch + a.w2 + 2 * qd);
-		if (2 * j + 1 < a.h) {
-			r.dl = *reinterpret_cast<const int2 *>(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
-			r.dh = *reinterpret_cast<const int2 *>(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
+		r.sl = ld2(llp + (long)j * a.spitch + 2 * qd);
+		if (det16) {
+			r.sh = ld2(det16 + (long)j * a.dpitch + a.w2 + 2 * qd);
+			if (2 * j + 1 < a.h) {
+				r.dl = ld2(det16 + (long)(a.h2 + j) * a.dpitch + 2 * qd);
+				r.dh = ld2(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
+			}
+		} else {
+			r.sh = ld2(det + (long)j * a.dpitch + a.w2 + 2 * qd);
+			if (2 * j + 1 < a.h) {
+				r.dl = ld2(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
+				r.dh = ld2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
+			}
 		}
 	}
 	return r;
@@ -744,6 +775,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
 	const int *llp = a.src + plane * a.src_ps;
 	const int *det = a.det + plane * a.det_ps;
+	const short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;
 	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
 	const bool h_odd = a.h & 1;
 
@@ -757,14 +789,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 
 	I2 pdl = { 0, 0 }, pdh = { 0, 0 };
 	if (j0 > 0) {
-		const InvRaw p = inv_load_w(a, llp, det, j0 - 1, qd, valid);
+		const InvRaw p = inv_load_w(a, llp, det, det16, j0 - 1, qd, valid);
 		pdl = to_i2(p.dl);
 		pdh = to_i2(p.dh);
 	}
 	// the subband rows of the next two row pairs are kept in flight (see k_fwd_level_w)
-	InvRaw cur = inv_load_w(a, llp, det, j0, qd, valid);
-	InvRaw nxt = inv_load_w(a, llp, det, j0 + 1, qd, valid);
-	InvRaw nx2 = inv_load_w(a, llp, det, j0 + 2, qd, valid);
+	InvRaw cur = inv_load_w(a, llp, det, det16, j0, qd, valid);
+	InvRaw nxt = inv_load_w(a, llp, det, det16, j0 + 1, qd, valid);
+	InvRaw nx2 = inv_load_w(a, llp, det, det16, j0 + 2, qd, valid);
 	I2 dl = to_i2(cur.dl), dh = to_i2(cur.dh);
 	I2 el = even_of(j0, to_i2(cur.sl), pdl, dl), eh = even_of(j0, to_i2(cur.sh), pdh, dh);
 	for (int jj = j0; jj < j1; ++jj) {
@@ -772,7 +804,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 		const InvRaw n = nxt;
 		nxt = nx2;
 		if (jj + 2 < j1)
-			nx2 = inv_load_w(a, llp, det, jj + 3, qd, valid);
+			nx2 = inv_load_w(a, llp, det, det16, jj + 3, qd, valid);
 		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el, neh = eh;   // mirror x[h] := x[h-2]
 		if (r1 + 1 < a.h) {
 			ndl = to_i2(n.dl);
@@ -858,10 +890,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	const bool valid = qd >= 0 && qd < A.nquads;
 	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
 	const int *llp[3], *det[3];
+	const short *det16[3];
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
 		llp[c] = a.src + (long)(3 * image + c) * a.src_ps;
 		det[c] = a.det + (long)(3 * image + c) * a.det_ps;
+		det16[c] = a.det16 ? a.det16 + (long)(3 * image + c) * a.det_ps : nullptr;
 	}
 	uint8_t *dst = a.dst8 + image * a.ll_ps;
 	const bool h_odd = a.h & 1;
@@ -880,12 +914,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	for (int c = 0; c < 3; ++c) {
 		I2 pdl = { 0, 0 }, pdh = { 0, 0 };
 		if (j0 > 0) {
-			const InvRaw p = inv_load_w(a, llp[c], det[c], j0 - 1, qd, valid);
+			const InvRaw p = inv_load_w(a, llp[c], det[c], det16[c], j0 - 1, qd, valid);
 			pdl = to_i2(p.dl);
 			pdh = to_i2(p.dh);
 		}
-		const InvRaw cur = inv_load_w(a, llp[c], det[c], j0, qd, valid);
-		nxt[c] = inv_load_w(a, llp[c], det[c], j0 + 1, qd, valid);
+		const InvRaw cur = inv_load_w(a, llp[c], det[c], det16[c], j0, qd, valid);
+		nxt[c] = inv_load_w(a, llp[c], det[c], det16[c], j0 + 1, qd, valid);
 		dl[c] = to_i2(cur.dl);
 		dh[c] = to_i2(cur.dh);
 		el[c] = even_of(j0, to_i2(cur.sl), pdl, dl[c]);
@@ -898,7 +932,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 		for (int c = 0; c < 3; ++c) {
 			const InvRaw n = nxt[c];
 			if (jj + 1 < j1)
-				nxt[c] = inv_load_w(a, llp[c], det[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
+				nxt[c] = inv_load_w(a, llp[c], det[c], det16[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
 			I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el[c], neh = eh[c];     // mirror x[h] := x[h-2]
 			if (r1 + 1 < a.h) {
 				ndl = to_i2(n.dl);
@@ -1221,7 +1255,7 @@ static int pick_rpw(int strips_x, int h2, int nplanes)
 // in8 != nullptr: the source is 8-bit pixels, gray (in8_channels 1: plane p = image p) or interleaved RGB
 // (in8_channels 3: plane p = channel p%3 of image p/3 after YCoCg-R); needs a finest level the wide kernel takes
 static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int in8_channels, int W, int H, int nplanes,
-	const dwtx_hist_sink *sink = nullptr, unsigned *hist_levels = nullptr)
+	const dwtx_hist_sink *sink = nullptr, unsigned *hist_levels = nullptr, int16_t *fine16 = nullptr)
 {
 	if (hist_levels)
 		*hist_levels = 0u;
@@ -1310,6 +1344,12 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 		a.det = out;
 		a.det_ps = full_ps;
 		a.dpitch = W;
+		a.det16 = nullptr;
+		if (fine16 && t == 0) {
+			if (!bytes_in || !aligned_to(fine16, 4))   // (8-bit sources only: that is what bounds the ring's magnitudes)
+				return DWTX_ERR_ARG;
+			a.det16 = fine16;
+		}
 		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 &&
 			(bytes_in ? aligned_to(a.src8, 4) : aligned_to(a.src, 16)) &&
 			a.llpitch % 2 == 0 && a.ll_ps % 2 == 0 && aligned_to(a.ll, 8) &&
@@ -1377,11 +1417,12 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride)
 	return W % 4 == 0 && (W > TAIL_MAX || H > TAIL_MAX) && image_stride % 4 == 0 && aligned_to(pix, 4);
 }
 
-int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels)
+int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels,
+	int16_t *fine16)
 {
 	if (!pix || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, (size_t)W * H * C))
 		return DWTX_ERR_ARG;
-	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C, sink, hist_levels);
+	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C, sink, hist_levels, fine16);
 }
 
 int dwtx_transformation_fwd_hist(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes, const dwtx_hist_sink *sink,
@@ -1401,7 +1442,8 @@ int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int
 
 // out8 != nullptr: the finest level writes clamped 8-bit pixels (gray, or interleaved RGB after the
 // inverse colour transform when out8_channels == 3), image i at out8 + i*out8_ps
-static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, int out8_channels, const int32_t *in, int W, int H, int nplanes)
+static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, int out8_channels, const int32_t *in, int W, int H, int nplanes,
+	const int16_t *fine16 = nullptr)
 {
 	if (!ctx || (!out && !out8) || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -1484,6 +1526,12 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 		a.det = const_cast<int *>(in);
 		a.det_ps = full_ps;
 		a.dpitch = W;
+		a.det16 = nullptr;
+		if (fine16 && t == 0) {
+			if (!bytes_out || !aligned_to(fine16, 4))
+				return DWTX_ERR_ARG;
+			a.det16 = const_cast<short *>(fine16);
+		}
 		const bool wide = a.w % 4 == 0 && a.llpitch % 4 == 0 && a.ll_ps % 4 == 0 &&
 			(bytes_out ? aligned_to(a.dst8, 4) : aligned_to(a.ll, 16)) &&
 			a.spitch % 2 == 0 && a.src_ps % 2 == 0 && aligned_to(a.src, 8) &&
@@ -1522,9 +1570,9 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 	return lift_inv(ctx, out, nullptr, 0, 0, in, W, H, nplanes);
 }
 
-int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n)
+int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n, const int16_t *fine16)
 {
 	if (!pix || W < 2 || H < 2 || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, image_stride))
 		return DWTX_ERR_ARG;
-	return lift_inv(ctx, nullptr, pix, (long)image_stride, C, in, W, H, n * C);
+	return lift_inv(ctx, nullptr, pix, (long)image_stride, C, in, W, H, n * C, fine16);
 }

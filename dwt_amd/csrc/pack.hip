@@ -67,6 +67,7 @@ struct PackGeom {
 	int levels, C, W, H;
 	long total;
 	const int *pyr;        // wavelet pyramid of the same planes (pitch W), or null
+	const short *fine16;   // or null: the finest ring (level levels-1) is not in pyr but here, as 16-bit coefficients (same pitch and positions)
 	unsigned sq_levels;    // ring levels whose tiles are read from the pyramid's 32x32 squares instead of `lin` (hilbert_dev.h)
 	int side[DWTX_MAX_LEVELS + 1];          // outer side of ring level l (lengths[l+1])
 	int pixels[DWTX_MAX_LEVELS + 1];
@@ -198,7 +199,10 @@ __device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__rest
 	int nv, unsigned *lds, int (&val)[16])
 {
 	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {   // uniform
-		load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
+		if (g.fine16 && l == g.levels - 1)
+			load_square16(g.fine16 + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
+		else
+			load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
 		return;
 	}
 	const int tbase = g.tile_base[tile];
@@ -277,14 +281,29 @@ __device__ __forceinline__ void hist_load(const PackGeom &g, const int *__restri
 		// the tile is a 32x32 square of the pyramid (hilbert_dev.h); a histogram does not care about the order:
 		// every lane takes four consecutive coefficients of four rows
 		const SquareMap m = square_map(g.side[l], (unsigned)g.tile_blk[tile]);
-		const int *sq = g.pyr + (long)plane * g.total + (long)(m.my & ~31u) * g.W + (m.mx & ~31u);
+		const long at = (long)plane * g.total + (long)(m.my & ~31u) * g.W + (m.mx & ~31u);
+		if (g.fine16 && l == g.levels - 1) {   // 16-bit rows: eight coefficients of two rows
+			const short *sq = g.fine16 + at;
 #pragma unroll
-		for (int it = 0; it < 4; ++it) {
-			const int4 v4 = *reinterpret_cast<const int4 *>(sq + (long)(it * 8 + (lane >> 3)) * g.W + (lane & 7) * 4);
-			val[4 * it] = v4.x;
-			val[4 * it + 1] = v4.y;
-			val[4 * it + 2] = v4.z;
-			val[4 * it + 3] = v4.w;
+			for (int it = 0; it < 2; ++it) {
+				const uint4 v4 = *reinterpret_cast<const uint4 *>(sq + (long)(it * 16 + (lane >> 2)) * g.W + (lane & 3) * 8);
+				const unsigned u[4] = { v4.x, v4.y, v4.z, v4.w };
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					val[8 * it + 2 * k] = (int)(short)(u[k] & 0xffffu);
+					val[8 * it + 2 * k + 1] = (int)u[k] >> 16;
+				}
+			}
+		} else {
+			const int *sq = g.pyr + at;
+#pragma unroll
+			for (int it = 0; it < 4; ++it) {
+				const int4 v4 = *reinterpret_cast<const int4 *>(sq + (long)(it * 8 + (lane >> 3)) * g.W + (lane & 7) * 4);
+				val[4 * it] = v4.x;
+				val[4 * it + 1] = v4.y;
+				val[4 * it + 2] = v4.z;
+				val[4 * it + 3] = v4.w;
+			}
 		}
 	} else {
 		// the same freedom on the linearised plane: the wave reads the tile front to back (lane-serial loads,
@@ -2335,6 +2354,7 @@ static int pack_geometry(dwtx_ctx *ctx, int W, int H, int C, int n, PackGeom &g,
 		g.side[g.levels] = 0;
 	}
 	g.pyr = nullptr;
+	g.fine16 = nullptr;
 	g.sq_levels = 0;
 	g.C = C;
 	g.W = W;
@@ -2386,7 +2406,7 @@ int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *s
 // pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
 // 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
 int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C,
-	int n, long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info)
+	int n, long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info, const int16_t *fine16)
 {
 	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
 		return DWTX_ERR_ARG;
@@ -2404,6 +2424,9 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	}
 	g.pyr = pyr;
 	g.sq_levels = sq_levels;
+	g.fine16 = fine16;
+	if (fine16 && (!((sq_levels >> (g.levels - 1)) & 1u) || ((uintptr_t)fine16 & 15)))   // (its whole squares only: the cut blocks come through lin)
+		return DWTX_ERR_ARG;
 	const int NT = tiles.NT;
 	// k_hist counts the tiles of the levels the forward transform has not done; when those are the coarse levels only (the
 	// finest ones are a suffix of the tiles) its grid ends there

@@ -446,6 +446,66 @@ def test_whole_squares_are_read_and_written_in_the_pyramid(ctx, shape, opts):
         assert (outs2[i] == outs[i]).all()
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 1), (128, 192, 3), (270, 480, 3), (256, 256, 1), (1080, 1920, 3)])
+def test_the_finest_ring_in_16_bit_planes_changes_nothing(ctx, shape, opts):
+    """From 8-bit pixels the codec keeps the finest ring's coefficients (|c| <= 1020, cdf53.h:13-21 on |x| <= 255) as
+    16-bit values in planes of their own: the transform writes and the entropy stage reads half
+    the bytes for three quarters of the coefficients.  Same bytes and pictures as the oracle (the other tests run this
+    way by default), extremes included, and the same as with the ring in the int32 pyramid (no_fine16)."""
+    H, W, Cn = shape
+    rng = np.random.default_rng(7)
+    extremes = (rng.integers(0, 2, (H, W, Cn)) * 255).astype(np.uint8)           # black / white noise: the largest details there are
+    checker = (((np.arange(H)[:, None] + np.arange(W)[None, :]) & 1) * 255).astype(np.uint8)[..., None].repeat(Cn, 2)
+    pixs = np.stack([orc.synth(W, H, Cn, 5, 0), orc.synth(W, H, Cn, 6, 1), extremes, np.ascontiguousarray(checker)])
+    want = [orc.encode(p)[0] for p in pixs] if W * H <= 512 * 512 else None
+    streams, stats = ctx.encode(pixs)
+    if want:
+        assert streams == want
+    outs = ctx.decode(streams)
+    assert all((o == p).all() for o, p in zip(outs, pixs))
+    cut = [s[: len(s) * (i + 2) // 6] for i, s in enumerate(streams)]    # cut streams: some keep the full size (bias on the finest ring)
+    outs_cut = ctx.decode(cut)
+    opts.set("no_fine16", 1)
+    streams32, stats32 = ctx.encode(pixs)
+    assert streams32 == streams and [s.total_bits for s in stats32] == [s.total_bits for s in stats]
+    outs32 = ctx.decode(streams)
+    assert all((o == p).all() for o, p in zip(outs32, pixs))
+    for a, b in zip(ctx.decode(cut), outs_cut):
+        assert (a is None and b is None) or (a.shape == b.shape and (a == b).all())
+    if W * H <= 512 * 512:
+        for c, o in zip(cut, outs_cut):
+            ref = orc.decode(c)
+            assert (ref is None and o is None) or (o.shape == ref.shape and (o == ref).all())
+
+
+@pytest.mark.parametrize("case", [(64, 64, 1, 15), (64, 64, 1, 16), (128, 96, 3, 15), (128, 96, 3, 16), (192, 128, 1, 12)])
+def test_streams_with_15_or_16_bit_planes_on_the_finest_ring_decode_like_the_oracle(ctx, case):
+    """No 8-bit source produces them, but a .dwt may hold them (encode.c:112-131 takes any int): streams coded by the
+    oracle from arbitrary coefficient planes with magnitudes up to 2^bits - 1 on every ring.  15 bits still fit the
+    16-bit planes the decoder keeps the finest ring in, 16 do not: a part of the batch with such a stream stays in
+    the int32 pyramid (unpack.hip).  Whole, cut (bias on large values) and in mixed batches."""
+    W, H, Cn, bits = case
+    rng = np.random.default_rng(bits * 1000 + W)
+    lin = np.zeros((Cn, W * H), dtype=np.int32)
+    for c in range(Cn):
+        k = W * H // 3
+        at = rng.choice(W * H, k, replace=False)
+        mag = rng.integers(1, 1 << rng.integers(1, bits + 1, k), k)
+        lin[c, at] = mag * rng.choice([-1, 1], k)
+        lin[c, rng.choice(W * H, 8, replace=False)] = ((1 << bits) - 1) * rng.choice([-1, 1], 8)   # the largest there is, both signs
+        lin[c, W * H - 5:] = [(1 << bits) - 1, -((1 << bits) - 1), 1, -1, 0]                       # and on the finest ring for sure
+    blob, _ = orc.encode_lin(lin, W, H)
+    st = orc.decode_stage(blob, W, H, Cn, -1)
+    assert st is not None and max(st[3]) == bits and (st[0] == lin).all()
+    good, _ = orc.encode(orc.synth(W, H, Cn, 3, 0))
+    cut = blob[: len(blob) * 4 // 5]
+    for batch in ([blob], [cut], [good, blob, cut, good], [blob] * 5 + [good] * 4 + [cut]):
+        outs = ctx.decode(batch)
+        for b, o in zip(batch, outs):
+            r = orc.decode(b)
+            assert (r is None and o is None) or (o is not None and o.shape == r.shape and (o == r).all()), len(batch)
+
+
 @pytest.mark.parametrize("parts", ["2", "3", "4"])
 def test_decode_batches_in_two_three_or_four_parts(ctx, parts, opts):
     """A decode batch runs as parts on streams of their own (unpack.hip dwtx_decode_planes_ex; four from 24 images on):
