@@ -380,18 +380,19 @@ __device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<int>, const int *__restrict_
 // are widened when used: two registers per row in flight instead of seven)
 struct FwdRaw8 {
 	unsigned v;       // pixels 4q .. 4q+3
-	unsigned edge;    // x[4q+4] (lane 63) | x[4q-2] << 8 | x[4q-1] << 16 (lane 0)
+	unsigned edge;    // the word after them (lane 63: its first byte is x[4q+4]) or before them (lane 0: its last two are x[4q-2], x[4q-1])
 };
 
+// (the edge word stays as it was loaded, like the pixels: anything computed from it here would make the wave wait for
+// the load — and for every load and store before it — two iterations before the row is used)
 __device__ __forceinline__ FwdRaw8 fwd_load_w(SrcTag<uint8_t>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int)
 {
 	FwdRaw8 r;
 	r.v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
 	r.edge = 0;
-	if (lane == 63 && valid && q + 1 < nquads)
-		r.edge = row[4 * q + 4];
-	if (lane == 0 && valid && q > 0)
-		r.edge = (unsigned)row[4 * q - 2] << 8 | (unsigned)row[4 * q - 1] << 16;
+	const bool left = lane == 0 && valid && q > 0, right = lane == 63 && valid && q + 1 < nquads;
+	if (left || right)
+		r.edge = *reinterpret_cast<const unsigned *>(row + 4 * q + (left ? -4 : 4));
 	return r;
 }
 
@@ -401,7 +402,7 @@ __device__ __forceinline__ FwdRaw fwd_widen(const FwdRaw8 &r, int)
 	FwdRaw o;
 	o.x = make_int4((int)(r.v & 255u), (int)((r.v >> 8) & 255u), (int)((r.v >> 16) & 255u), (int)(r.v >> 24));
 	o.xr = (int)(r.edge & 255u);
-	o.left = make_int2((int)((r.edge >> 8) & 255u), (int)(r.edge >> 16));
+	o.left = make_int2((int)((r.edge >> 16) & 255u), (int)(r.edge >> 24));
 	return o;
 }
 
@@ -688,36 +689,364 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	}
 }
 
-struct InvRaw {
-	int2 sl, sh, dl, dh;   // LL | HL | LH | HH samples of one row pair
+// ---- the finest level from 8-bit pixels, in packed 16-bit arithmetic ----
+// Samples of magnitude <= 255 cannot leave 16 bits anywhere in one level of cdf53.h:9-34 (|d| <= 510 after the row
+// pass, <= 1020 after the column pass; every intermediate sum stays below 2^12): the lane's two column pairs ride in
+// the halves of one register and every add / shift / subtract is a v_pk_* instruction on both.  Same results as
+// k_fwd_level_w<uint8_t / Rgb8>, which this replaces (about half its vector instructions).
+typedef short P2 __attribute__((ext_vector_type(2)));
+typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ P2 p2_of(unsigned u) { return __builtin_bit_cast(P2, u); }
+__device__ __forceinline__ unsigned bits_of(P2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ P2 tdiv2p(P2 a) { return (a + (P2)((U2)a >> (U2)15)) >> (P2)1; }
+__device__ __forceinline__ P2 tdiv4p(P2 a) { return (a + ((a >> (P2)15) & (P2)3)) >> (P2)2; }
+__device__ __forceinline__ I2 i2_of(P2 v)
+{
+	I2 r = { (int)v.x, (int)v.y };
+	return r;
+}
+
+// image.h:52-65 on two pixels at once: channel ch of (R, G, B) pairs
+__device__ __forceinline__ P2 ycocg_p(P2 r, P2 g, P2 b, int ch)
+{
+	const P2 co = r - b;
+	const P2 t = b + tdiv2p(co);
+	const P2 cg = g - t;
+	return ch == 0 ? t + tdiv2p(cg) : ch == 1 ? co : cg;
+}
+
+// one row's samples of this lane as packed pairs: E = (x[4q], x[4q+2]), O = (x[4q+1], x[4q+3]); xr = x[4q+4] in its low
+// half (lane 63 only), left = (x[4q-2], x[4q-1]) (lane 0 only)
+struct RowP {
+	P2 E, O, xr, left;
+};
+
+__device__ __forceinline__ RowP row_p(const FwdRaw8 &r, int)
+{
+	RowP o;
+	o.E = p2_of(r.v & 0x00ff00ffu);
+	o.O = p2_of((r.v >> 8) & 0x00ff00ffu);
+	o.xr = p2_of(r.edge & 255u);
+	o.left = p2_of(__builtin_amdgcn_perm(0u, r.edge, 0x0c030c02u));   // the last two bytes of the word before
+	return o;
+}
+
+__device__ __forceinline__ RowP row_p(const FwdRawRgb &r, int ch)
+{
+	// a = R0 G0 B0 R1, b = G1 B1 R2 G2, c = B2 R3 G3 B3 (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c is zero)
+	RowP o;
+	o.E = ycocg_p(p2_of(__builtin_amdgcn_perm(r.b, r.a, 0x0c060c00u)), p2_of(__builtin_amdgcn_perm(r.b, r.a, 0x0c070c01u)),
+		p2_of(__builtin_amdgcn_perm(r.c, r.a, 0x0c040c02u)), ch);
+	o.O = ycocg_p(p2_of(__builtin_amdgcn_perm(r.c, r.a, 0x0c050c03u)), p2_of(__builtin_amdgcn_perm(r.c, r.b, 0x0c060c00u)),
+		p2_of(__builtin_amdgcn_perm(r.c, r.b, 0x0c070c01u)), ch);
+	// lane 63: e0 = R4 G4 B4 ..; lane 0: e0, e1 = bytes 12q-8 .. 12q-1, pixels 4q-2 and 4q-1 are the last six
+	o.xr = ycocg_p(p2_of(r.e0 & 255u), p2_of((r.e0 >> 8) & 255u), p2_of((r.e0 >> 16) & 255u), ch);
+	o.left = ycocg_p(p2_of(__builtin_amdgcn_perm(r.e1, r.e0, 0x0c050c02u)), p2_of(__builtin_amdgcn_perm(r.e1, r.e0, 0x0c060c03u)),
+		p2_of(__builtin_amdgcn_perm(r.e1, r.e0, 0x0c070c04u)), ch);
+	return o;
+}
+
+// cdf53.h:9-34 along the row for the lane's two pairs: L = (s[2q], s[2q+1]), Hh = (d[2q], d[2q+1])
+__device__ __forceinline__ void fwd_lift_p(const RowP &r, int q, int lane, int nquads, P2 &L, P2 &Hh)
+{
+	const unsigned e = bits_of(r.E);
+	unsigned nx = (unsigned)__shfl_down((int)e, 1);          // the next lane's (x[4q+4], ..)
+	if (lane == 63)
+		nx = bits_of(r.xr);
+	if (q + 1 >= nquads)
+		nx = e >> 16;                                        // x[w] := x[w-2]
+	const P2 En = p2_of(__builtin_amdgcn_alignbit(nx, e, 16));   // (x[4q+2], x[4q+4])
+	const P2 D = r.O - tdiv2p(r.E + En);
+	const unsigned d = bits_of(D);
+	unsigned pv = (unsigned)__shfl_up((int)d, 1);            // high half: the previous lane's d[2q-1]
+	if (lane == 0) {
+		const P2 dm = r.left.yy - tdiv2p(r.left.xx + r.E.xx);   // d[2q-1] from the two samples before the strip
+		pv = bits_of(dm) << 16;
+	}
+	if (q == 0)
+		pv = d << 16;                                        // d[-1] := d[0]
+	const P2 Dl = p2_of(__builtin_amdgcn_alignbit(d, pv, 16));   // (d[2q-1], d[2q])
+	L = r.E + tdiv4p(Dl + D);
+	Hh = D;
+}
+
+__device__ __forceinline__ void hist_add2(HistAcc &h, P2 v)
+{
+	const unsigned a = bits_of(__builtin_elementwise_max(v, -v));   // both magnitudes (below 2^12)
+	h.mx |= a;
+	const unsigned t0 = 32u - (unsigned)__clz((int)(a & 0xffffu)), t1 = 32u - (unsigned)__clz((int)(a >> 16));
+	h.R += 0x1111111111111111ull << (4u * t0);
+	h.R += 0x1111111111111111ull << (4u * t1);
+}
+
+__device__ __forceinline__ void st2(int *p, P2 v) { *reinterpret_cast<int2 *>(p) = make_int2((int)v.x, (int)v.y); }
+__device__ __forceinline__ void st2(short *p, P2 v) { *reinterpret_cast<unsigned *>(p) = bits_of(v); }
+
+// Rows for the batched loop below: every lane loads — lanes beyond the row from the row's last quad, the edge word from
+// a clamped place — so that no load sits behind a branch or feeds a select (either would make the wave wait for it at
+// once); what the extra lanes get is never used.  e8: byte offset of the lane's edge word in a row (the word before the
+// lane's pixels for lane 0, the word after them for the others), the same for every row.
+struct LaneAt {
+	int main, edge;   // byte offsets in a source row
+};
+
+__device__ __forceinline__ LaneAt lane_at(SrcTag<uint8_t>, int q, int lane, int nquads)
+{
+	const int qa = min(q, nquads - 1);
+	LaneAt o = { 4 * qa, lane == 0 ? max(4 * qa - 4, 0) : min(4 * qa + 4, 4 * (nquads - 1)) };
+	return o;
+}
+
+__device__ __forceinline__ LaneAt lane_at(SrcTag<Rgb8>, int q, int lane, int nquads)
+{
+	const int qa = min(q, nquads - 1);
+	LaneAt o = { 12 * qa, lane == 0 ? max(12 * qa - 8, 0) : min(12 * qa + 12, 12 * nquads - 8) };
+	return o;
+}
+
+__device__ __forceinline__ FwdRaw8 fwd_load_p(SrcTag<uint8_t>, const uint8_t *__restrict__ row, const LaneAt &at)
+{
+	FwdRaw8 r;
+	r.v = *reinterpret_cast<const unsigned *>(row + at.main);
+	r.edge = *reinterpret_cast<const unsigned *>(row + at.edge);
+	return r;
+}
+
+// (the RGB row as the two loads deliver it — three words and two words in consecutive registers; taking single words
+// out of them at load time would be a use of the load)
+typedef unsigned U32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned U32x2 __attribute__((ext_vector_type(2)));
+struct FwdRawRgbP {
+	U32x3 abc;   // pixels 4q .. 4q+3
+	U32x2 e;     // lane 63: e.x = the word with pixel 4q+4; lane 0: bytes 12q-8 .. 12q-1
+};
+
+__device__ __forceinline__ FwdRawRgbP fwd_load_p(SrcTag<Rgb8>, const uint8_t *__restrict__ row, const LaneAt &at)
+{
+	FwdRawRgbP r;
+	r.abc = *reinterpret_cast<const U32x3 *>(row + at.main);
+	r.e = *reinterpret_cast<const U32x2 *>(row + at.edge);
+	return r;
+}
+
+// a row moves from the registers it was loaded into to the registers it is used from: a move the register allocator
+// cannot fold away, placed where the wave is to wait for the row
+__device__ __forceinline__ unsigned hold(unsigned v)
+{
+	unsigned o;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
+	return o;
+}
+__device__ __forceinline__ FwdRaw8 hold(const FwdRaw8 &r)
+{
+	FwdRaw8 o = { hold(r.v), hold(r.edge) };
+	return o;
+}
+__device__ __forceinline__ FwdRawRgb hold(const FwdRawRgbP &r)
+{
+	FwdRawRgb o = { hold(r.abc.x), hold(r.abc.y), hold(r.abc.z), hold(r.e.x), hold(r.e.y) };
+	return o;
+}
+__device__ __forceinline__ FwdRawRgb as_used(const FwdRawRgbP &r)
+{
+	FwdRawRgb o = { r.abc.x, r.abc.y, r.abc.z, r.e.x, r.e.y };
+	return o;
+}
+__device__ __forceinline__ FwdRaw8 as_used(const FwdRaw8 &r) { return r; }
+
+// the row as it is loaded / as it is used
+template <typename SrcT>
+struct RowRegs {
+	typedef FwdRaw8 Loaded;
+	typedef FwdRaw8 Used;
+};
+template <>
+struct RowRegs<Rgb8> {
+	typedef FwdRawRgbP Loaded;
+	typedef FwdRawRgb Used;
+};
+
+template <typename SrcT, bool HIST>
+__global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
+{
+	const LevelArgs &a = A.a;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int bx, by, chan = 0;
+	if (IsRgb<SrcT>::value)
+		xcd_strip_rgb(bx, by, chan);
+	else
+		xcd_strip(bx, by);
+	const int sx = (bx << A.wx_log2) + (wv & ((1 << A.wx_log2) - 1));
+	const int q = sx * 64 + lane;
+	const int j0 = (by * (WAVES >> A.wx_log2) + (wv >> A.wx_log2)) * a.rpw;
+	if (j0 >= a.h2 || sx * 64 >= A.nquads)
+		return;
+	const int j1 = min(j0 + a.rpw, a.h2);
+	const int plane = IsRgb<SrcT>::value ? (int)blockIdx.z * 3 + chan : (int)blockIdx.z;
+	const bool valid = q < A.nquads;
+	int ch;
+	const uint8_t *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
+	int *ll = a.ll + plane * a.ll_ps;
+	int *det = a.det + plane * a.det_ps;
+	short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;   // (uniform)
+
+	// Memory operations retire in order on this part (one counter for loads and stores): a wave that waits for rows it
+	// loaded also waits for everything it issued before them, and a wait the compiler cannot count exactly waits for
+	// everything.  So the loop works in batches of S row pairs: wait once, send the previous batch's results out, ask
+	// for the next batch's rows, then compute S row pairs without touching memory — by the next wait both the stores
+	// and the loads are a whole batch of arithmetic old.
+	constexpr int S = 2;
+	const int jfirst = j0 > 0 ? j0 - 1 : 0;
+	const P2 zero = p2_of(0u);
+	P2 l0, h0, pl = zero, ph = zero;
+	const LaneAt at = lane_at(SrcTag<SrcT>(), q, lane, A.nquads);
+	{
+		const typename RowRegs<SrcT>::Loaded r0 = fwd_load_p(SrcTag<SrcT>(), src + (long)(2 * jfirst) * a.spitch, at);
+		fwd_lift_p(row_p(as_used(r0), ch), q, lane, A.nquads, l0, h0);
+	}
+	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
+	typename RowRegs<SrcT>::Used cur[2 * S];
+	typename RowRegs<SrcT>::Loaded nxt[2 * S];
+#pragma unroll
+	for (int k = 0; k < 2 * S; ++k)
+		nxt[k] = fwd_load_p(SrcTag<SrcT>(), rowp(2 * jfirst + 1 + k), at);
+	P2 osl[S], osh[S], odl[S], odh[S];   // a batch's results wait here for the next iteration's stores
+	auto store_batch = [&](int jb) {
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int j = jb + s;
+			if (j >= j0 && j < j1 && valid) {
+				const bool odd_in = 2 * j + 1 < a.h;
+				st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
+				if (det16) {
+					st2(det16 + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
+					if (odd_in) {
+						st2(det16 + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
+						st2(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+					}
+				} else {
+					st2(det + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
+					if (odd_in) {
+						st2(det + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
+						st2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+					}
+				}
+			}
+		}
+	};
+	HistAcc hHL = { 0, 0, 0, 0 }, hLH = { 0, 0, 0, 0 }, hHH = { 0, 0, 0, 0 };
+	for (int jb = jfirst; jb < j1; jb += S) {
+#pragma unroll
+		for (int k = 0; k < 2 * S; ++k)
+			cur[k] = hold(nxt[k]);   // the one wait of the iteration: everything outstanding is a batch old
+		if (jb > jfirst)
+			store_batch(jb - S);
+		if (jb + S < j1) {
+#pragma unroll
+			for (int k = 0; k < 2 * S; ++k)
+				nxt[k] = fwd_load_p(SrcTag<SrcT>(), rowp(2 * (jb + S) + 1 + k), at);
+		}
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int jj = jb + s;
+			if (jj >= j1)
+				break;
+			const int r1 = 2 * jj + 1, r2 = r1 + 1;
+			const bool odd_in = r1 < a.h;
+			P2 l1 = zero, h1 = zero, l2 = l0, h2v = h0;
+			if (odd_in)
+				fwd_lift_p(row_p(cur[2 * s], ch), q, lane, A.nquads, l1, h1);
+			if (r2 < a.h)
+				fwd_lift_p(row_p(cur[2 * s + 1], ch), q, lane, A.nquads, l2, h2v);
+			const P2 dl = l1 - tdiv2p(l0 + l2);     // cdf53.h:13 down the columns
+			const P2 dh = h1 - tdiv2p(h0 + h2v);
+			P2 sl = l0, sh = h0;
+			if (odd_in) {
+				sl = l0 + tdiv4p((jj ? pl : dl) + dl);   // cdf53.h:20
+				sh = h0 + tdiv4p((jj ? ph : dh) + dh);
+			}
+			osl[s] = sl;
+			osh[s] = sh;
+			odl[s] = dl;
+			odh[s] = dh;
+			if (HIST && jj >= j0) {
+				// the detail coefficients of this row pair (cdf53.h:9-34 output): HL row jj, LH and HH row h2 + jj
+				if (valid) {
+					hist_add2(hHL, sh);
+					if (odd_in) {
+						hist_add2(hLH, dl);
+						hist_add2(hHH, dh);
+					}
+				}
+				if ((jj & 3) == 3) {   // eight coefficients per subband since the last fold: a nibble holds fifteen
+					hist_fold(hHL);
+					hist_fold(hLH);
+					hist_fold(hHH);
+				}
+				// a block ends where its 32 rows end (or the strip does): the rows of HL are jj, those of LH / HH h2 + jj
+				const bool last = jj == j1 - 1;
+				const int bxl = (2 * q) >> 5, bxh = (a.w2 + 2 * q) >> 5;
+				if (last || ((jj + 1) & 31) == 0) {
+					hHL.mx = (hHL.mx | (hHL.mx >> 16)) & 0xffffu;
+					hist_flush(hHL, A.hist, plane, bxh, jj >> 5, lane);
+				}
+				if (last || ((a.h2 + jj + 1) & 31) == 0) {
+					hLH.mx = (hLH.mx | (hLH.mx >> 16)) & 0xffffu;
+					hHH.mx = (hHH.mx | (hHH.mx >> 16)) & 0xffffu;
+					hist_flush(hLH, A.hist, plane, bxl, (a.h2 + jj) >> 5, lane);
+					hist_flush(hHH, A.hist, plane, bxh, (a.h2 + jj) >> 5, lane);
+				}
+			}
+			pl = dl;
+			ph = dh;
+			l0 = l2;
+			h0 = h2v;
+		}
+	}
+	// the last batch (a strip has at least one row pair)
+	store_batch(jfirst + (j1 - 1 - jfirst) / S * S);
+}
+
+// LL | HL | LH | HH samples of one row pair as they were loaded (F16: the detail bands are words of two 16-bit values;
+// they are widened when used — anything computed at load time would make the wave wait for the load right there)
+template <bool F16>
+struct InvRawT {
+	int2 sl, sh, dl, dh;
+};
+template <>
+struct InvRawT<true> {
+	int2 sl;
+	unsigned sh, dl, dh;
 };
 
 __device__ __forceinline__ int2 ld2(const int *p) { return *reinterpret_cast<const int2 *>(p); }
-__device__ __forceinline__ int2 ld2(const short *p)
-{
-	const unsigned u = *reinterpret_cast<const unsigned *>(p);
-	return make_int2((int)(short)(u & 0xffffu), (int)u >> 16);
-}
 
-// det16 (uniform): the detail bands as 16-bit values, plane `det16` instead of `det`
-__device__ __forceinline__ InvRaw inv_load_w(const LevelArgs &a, const int *llp, const int *det, const short *det16, int j, int qd, bool valid)
+__device__ __forceinline__ InvRawT<false> inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, int qd, bool valid)
 {
-	InvRaw r;
+	InvRawT<false> r;
 	r.sl = r.sh = r.dl = r.dh = make_int2(0, 0);
 	if (valid && j < a.h2) {
 		r.sl = ld2(llp + (long)j * a.spitch + 2 * qd);
-		if (det16) {
-			r.sh = ld2(det16 + (long)j * a.dpitch + a.w2 + 2 * qd);
-			if (2 * j + 1 < a.h) {
-				r.dl = ld2(det16 + (long)(a.h2 + j) * a.dpitch + 2 * qd);
-				r.dh = ld2(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
-			}
-		} else {
-			r.sh = ld2(det + (long)j * a.dpitch + a.w2 + 2 * qd);
-			if (2 * j + 1 < a.h) {
-				r.dl = ld2(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
-				r.dh = ld2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
-			}
+		r.sh = ld2(det + (long)j * a.dpitch + a.w2 + 2 * qd);
+		if (2 * j + 1 < a.h) {
+			r.dl = ld2(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
+			r.dh = ld2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
+		}
+	}
+	return r;
+}
+
+__device__ __forceinline__ InvRawT<true> inv_load_w(const LevelArgs &a, const int *llp, const short *det16, int j, int qd, bool valid)
+{
+	InvRawT<true> r;
+	r.sl = make_int2(0, 0);
+	r.sh = r.dl = r.dh = 0u;
+	if (valid && j < a.h2) {
+		r.sl = ld2(llp + (long)j * a.spitch + 2 * qd);
+		r.sh = *reinterpret_cast<const unsigned *>(det16 + (long)j * a.dpitch + a.w2 + 2 * qd);
+		if (2 * j + 1 < a.h) {
+			r.dl = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + j) * a.dpitch + 2 * qd);
+			r.dh = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
 		}
 	}
 	return r;
@@ -728,6 +1057,24 @@ __device__ __forceinline__ I2 to_i2(int2 v)
 	I2 r = { v.x, v.y };
 	return r;
 }
+
+__device__ __forceinline__ I2 to_i2(unsigned u)   // two 16-bit values
+{
+	I2 r = { (int)(short)(u & 0xffffu), (int)u >> 16 };
+	return r;
+}
+
+// the plane's detail bands as the kernel variant reads them
+template <bool F16>
+struct DetPtr {
+	typedef const int *type;
+	static __device__ __forceinline__ type of(const LevelArgs &a, long plane) { return a.det + plane * a.det_ps; }
+};
+template <>
+struct DetPtr<true> {
+	typedef const short *type;
+	static __device__ __forceinline__ type of(const LevelArgs &a, long plane) { return a.det16 + plane * a.det_ps; }
+};
 
 // horizontal inverse of one output row for this lane's two pairs
 __device__ __forceinline__ void inv_store_w(int *__restrict__ row, int qd, int e0, int o0, int e1, int o1)
@@ -765,7 +1112,7 @@ __device__ __forceinline__ int *inv_dst<int>(const LevelArgs &a) { return a.ll; 
 template <>
 __device__ __forceinline__ uint8_t *inv_dst<uint8_t>(const LevelArgs &a) { return a.dst8; }
 
-template <typename DstT>
+template <typename DstT, bool F16>
 __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -781,8 +1128,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	const bool valid = qd >= 0 && qd < A.nquads;
 	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
 	const int *llp = a.src + plane * a.src_ps;
-	const int *det = a.det + plane * a.det_ps;
-	const short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;
+	const typename DetPtr<F16>::type det = DetPtr<F16>::of(a, plane);
+	typedef InvRawT<F16> InvRaw;
 	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
 	const bool h_odd = a.h & 1;
 
@@ -796,14 +1143,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 
 	I2 pdl = { 0, 0 }, pdh = { 0, 0 };
 	if (j0 > 0) {
-		const InvRaw p = inv_load_w(a, llp, det, det16, j0 - 1, qd, valid);
+		const InvRaw p = inv_load_w(a, llp, det, j0 - 1, qd, valid);
 		pdl = to_i2(p.dl);
 		pdh = to_i2(p.dh);
 	}
 	// the subband rows of the next two row pairs are kept in flight (see k_fwd_level_w)
-	InvRaw cur = inv_load_w(a, llp, det, det16, j0, qd, valid);
-	InvRaw nxt = inv_load_w(a, llp, det, det16, j0 + 1, qd, valid);
-	InvRaw nx2 = inv_load_w(a, llp, det, det16, j0 + 2, qd, valid);
+	InvRaw cur = inv_load_w(a, llp, det, j0, qd, valid);
+	InvRaw nxt = inv_load_w(a, llp, det, j0 + 1, qd, valid);
+	InvRaw nx2 = inv_load_w(a, llp, det, j0 + 2, qd, valid);
 	I2 dl = to_i2(cur.dl), dh = to_i2(cur.dh);
 	I2 el = even_of(j0, to_i2(cur.sl), pdl, dl), eh = even_of(j0, to_i2(cur.sh), pdh, dh);
 	for (int jj = j0; jj < j1; ++jj) {
@@ -811,7 +1158,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 		const InvRaw n = nxt;
 		nxt = nx2;
 		if (jj + 2 < j1)
-			nx2 = inv_load_w(a, llp, det, det16, jj + 3, qd, valid);
+			nx2 = inv_load_w(a, llp, det, jj + 3, qd, valid);
 		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el, neh = eh;   // mirror x[h] := x[h-2]
 		if (r1 + 1 < a.h) {
 			ndl = to_i2(n.dl);
@@ -882,6 +1229,7 @@ __device__ __forceinline__ void rgb_store_w(uint8_t *__restrict__ row, int qd, c
 		w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -896,13 +1244,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	const int image = blockIdx.z;
 	const bool valid = qd >= 0 && qd < A.nquads;
 	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
-	const int *llp[3], *det[3];
-	const short *det16[3];
+	const int *llp[3];
+	typename DetPtr<F16>::type det[3];
+	typedef InvRawT<F16> InvRaw;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
 		llp[c] = a.src + (long)(3 * image + c) * a.src_ps;
-		det[c] = a.det + (long)(3 * image + c) * a.det_ps;
-		det16[c] = a.det16 ? a.det16 + (long)(3 * image + c) * a.det_ps : nullptr;
+		det[c] = DetPtr<F16>::of(a, 3 * image + c);
 	}
 	uint8_t *dst = a.dst8 + image * a.ll_ps;
 	const bool h_odd = a.h & 1;
@@ -921,12 +1269,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	for (int c = 0; c < 3; ++c) {
 		I2 pdl = { 0, 0 }, pdh = { 0, 0 };
 		if (j0 > 0) {
-			const InvRaw p = inv_load_w(a, llp[c], det[c], det16[c], j0 - 1, qd, valid);
+			const InvRaw p = inv_load_w(a, llp[c], det[c], j0 - 1, qd, valid);
 			pdl = to_i2(p.dl);
 			pdh = to_i2(p.dh);
 		}
-		const InvRaw cur = inv_load_w(a, llp[c], det[c], det16[c], j0, qd, valid);
-		nxt[c] = inv_load_w(a, llp[c], det[c], det16[c], j0 + 1, qd, valid);
+		const InvRaw cur = inv_load_w(a, llp[c], det[c], j0, qd, valid);
+		nxt[c] = inv_load_w(a, llp[c], det[c], j0 + 1, qd, valid);
 		dl[c] = to_i2(cur.dl);
 		dh[c] = to_i2(cur.dh);
 		el[c] = even_of(j0, to_i2(cur.sl), pdl, dl[c]);
@@ -939,7 +1287,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 		for (int c = 0; c < 3; ++c) {
 			const InvRaw n = nxt[c];
 			if (jj + 1 < j1)
-				nxt[c] = inv_load_w(a, llp[c], det[c], det16[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
+				nxt[c] = inv_load_w(a, llp[c], det[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
 			I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el[c], neh = eh[c];     // mirror x[h] := x[h-2]
 			if (r1 + 1 < a.h) {
 				ndl = to_i2(n.dl);
@@ -1387,15 +1735,15 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 				A.hist.nbs = sink->tiles.nbs[level];
 				*hist_levels |= 1u << level;
 				if (bytes_in && in8_channels == 3)
-					hipLaunchKernelGGL((k_fwd_level_w<Rgb8, true>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
+					hipLaunchKernelGGL((k_fwd_pixels_w<Rgb8, true>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else if (bytes_in)
-					hipLaunchKernelGGL((k_fwd_level_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+					hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else
 					hipLaunchKernelGGL((k_fwd_level_w<int, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			} else if (bytes_in && in8_channels == 3)
-				hipLaunchKernelGGL((k_fwd_level_w<Rgb8, false>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_pixels_w<Rgb8, false>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_in)
-				hipLaunchKernelGGL((k_fwd_level_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
 				hipLaunchKernelGGL((k_fwd_level_w<int, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
@@ -1557,11 +1905,16 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
 			if (bytes_out && out8_channels == 3) {
 				grid.z = nplanes / 3;
-				hipLaunchKernelGGL(k_inv_level_w_rgb, grid, dim3(64 * WAVES), 0, ctx->stream, A);
-			} else if (bytes_out)
-				hipLaunchKernelGGL(k_inv_level_w<uint8_t>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				if (a.det16)
+					hipLaunchKernelGGL(k_inv_level_w_rgb<true>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				else
+					hipLaunchKernelGGL(k_inv_level_w_rgb<false>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			} else if (bytes_out && a.det16)
+				hipLaunchKernelGGL((k_inv_level_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else if (bytes_out)
+				hipLaunchKernelGGL((k_inv_level_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
-				hipLaunchKernelGGL(k_inv_level_w<int>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_inv_level_w<int, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, INV_PAIRS);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
