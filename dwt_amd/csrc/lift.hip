@@ -348,128 +348,24 @@ struct FwdRaw {
 	int2 left;        // x[4q-2], x[4q-1] for lane 0
 };
 
-// Where a forward level reads its samples: int32 planes (every level but possibly the finest), 8-bit
-// gray pixels (pnm.h:69-74 fused) or 8-bit interleaved RGB pixels, of which each plane's launch
-// takes its own YCoCg-R channel (image.h:52-65 fused).
+// Where the finest forward level may read its samples instead of int32 planes: 8-bit gray pixels (pnm.h:69-74 fused)
+// or 8-bit interleaved RGB pixels, of which each plane's launch takes its own YCoCg-R channel (image.h:52-65 fused).
 struct Rgb8 {};
 template <typename SrcT>
 struct SrcTag {};
-template <typename SrcT>
-struct SrcElem {
-	typedef SrcT type;
-};
-template <>
-struct SrcElem<Rgb8> {
-	typedef uint8_t type;
-};
 
-__device__ __forceinline__ FwdRaw fwd_load_w(SrcTag<int>, const int *__restrict__ row, int q, int lane, int nquads, bool valid, int)
-{
-	FwdRaw r;
-	r.x = valid ? *reinterpret_cast<const int4 *>(row + 4 * q) : make_int4(0, 0, 0, 0);
-	r.xr = 0;
-	r.left = make_int2(0, 0);
-	if (lane == 63 && valid && q + 1 < nquads)
-		r.xr = row[4 * q + 4];
-	if (lane == 0 && valid && q > 0)
-		r.left = *reinterpret_cast<const int2 *>(row + 4 * q - 2);
-	return r;
-}
-
-// (8-bit rows wait for their turn as they were loaded — four pixels in a word, the neighbours' three in another — and
-// are widened when used: two registers per row in flight instead of seven)
+// (8-bit rows wait for their turn as they were loaded — four pixels in a word, the neighbours' in another — and are
+// widened when used)
 struct FwdRaw8 {
 	unsigned v;       // pixels 4q .. 4q+3
 	unsigned edge;    // the word after them (lane 63: its first byte is x[4q+4]) or before them (lane 0: its last two are x[4q-2], x[4q-1])
 };
 
-// (the edge word stays as it was loaded, like the pixels: anything computed from it here would make the wave wait for
-// the load — and for every load and store before it — two iterations before the row is used)
-__device__ __forceinline__ FwdRaw8 fwd_load_w(SrcTag<uint8_t>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int)
-{
-	FwdRaw8 r;
-	r.v = valid ? *reinterpret_cast<const unsigned *>(row + 4 * q) : 0u;
-	r.edge = 0;
-	const bool left = lane == 0 && valid && q > 0, right = lane == 63 && valid && q + 1 < nquads;
-	if (left || right)
-		r.edge = *reinterpret_cast<const unsigned *>(row + 4 * q + (left ? -4 : 4));
-	return r;
-}
-
-__device__ __forceinline__ FwdRaw fwd_widen(const FwdRaw &r, int) { return r; }
-__device__ __forceinline__ FwdRaw fwd_widen(const FwdRaw8 &r, int)
-{
-	FwdRaw o;
-	o.x = make_int4((int)(r.v & 255u), (int)((r.v >> 8) & 255u), (int)((r.v >> 16) & 255u), (int)(r.v >> 24));
-	o.xr = (int)(r.edge & 255u);
-	o.left = make_int2((int)((r.edge >> 16) & 255u), (int)(r.edge >> 24));
-	return o;
-}
-
-
-
-// image.h:52-65: channel ch (0 Y, 1 Co, 2 Cg) of one RGB pixel
-__device__ __forceinline__ int ycocg_of(int r, int g, int b, int ch)
-{
-	const int co = r - b;
-	const int t = b + tdiv2(co);
-	const int cg = g - t;
-	return ch == 0 ? t + tdiv2(cg) : ch == 1 ? co : cg;
-}
-
-// (RGB rows wait packed as well: the four pixels' three words and two words of neighbours; the colour transform of
-// image.h:52-65 happens when the row is used)
+// (RGB rows too: the four pixels' three words and two words of neighbours; the colour transform of image.h:52-65
+// happens when the row is used)
 struct FwdRawRgb {
 	unsigned a, b, c;   // pixels 4q .. 4q+3
 	unsigned e0, e1;    // lane 63: e0 = the word with pixel 4q+4; lane 0: bytes 12q-8 .. 12q-1 (pixels 4q-2 and 4q-1 are the last six)
-};
-
-__device__ __forceinline__ FwdRawRgb fwd_load_w(SrcTag<Rgb8>, const uint8_t *__restrict__ row, int q, int lane, int nquads, bool valid, int ch)
-{
-	FwdRawRgb r;
-	// four pixels = twelve bytes = three aligned words (the row pitch 3*w is a multiple of 4)
-	const unsigned *w = reinterpret_cast<const unsigned *>(row + 12 * q);
-	r.a = valid ? w[0] : 0u;
-	r.b = valid ? w[1] : 0u;
-	r.c = valid ? w[2] : 0u;
-	r.e0 = r.e1 = 0u;
-	if (lane == 63 && valid && q + 1 < nquads)
-		r.e0 = w[3];
-	if (lane == 0 && valid && q > 0) {
-		r.e0 = *(w - 2);
-		r.e1 = *(w - 1);
-	}
-	return r;
-}
-
-__device__ __forceinline__ FwdRaw fwd_widen(const FwdRawRgb &r, int ch)
-{
-	FwdRaw o;
-	const unsigned a = r.a, b = r.b, c = r.c;
-	o.x.x = ycocg_of((int)(a & 255u), (int)((a >> 8) & 255u), (int)((a >> 16) & 255u), ch);
-	o.x.y = ycocg_of((int)(a >> 24), (int)(b & 255u), (int)((b >> 8) & 255u), ch);
-	o.x.z = ycocg_of((int)((b >> 16) & 255u), (int)(b >> 24), (int)(c & 255u), ch);
-	o.x.w = ycocg_of((int)((c >> 8) & 255u), (int)((c >> 16) & 255u), (int)(c >> 24), ch);
-	// (only lane 63 uses xr and only lane 0 uses left: whatever the other lanes make of their zero words is never read)
-	const unsigned n = r.e0;
-	o.xr = ycocg_of((int)(n & 255u), (int)((n >> 8) & 255u), (int)((n >> 16) & 255u), ch);
-	const unsigned m = r.e0, k = r.e1;
-	o.left = make_int2(ycocg_of((int)((m >> 16) & 255u), (int)(m >> 24), (int)(k & 255u), ch),
-		ycocg_of((int)((k >> 8) & 255u), (int)((k >> 16) & 255u), (int)(k >> 24), ch));
-	return o;
-}
-
-template <typename SrcT>
-struct RawOf {
-	typedef FwdRaw type;
-};
-template <>
-struct RawOf<uint8_t> {
-	typedef FwdRaw8 type;
-};
-template <>
-struct RawOf<Rgb8> {
-	typedef FwdRawRgb type;
 };
 
 __device__ __forceinline__ void fwd_lift_w(const FwdRaw &r, int q, int lane, int nquads, I2 &lo, I2 &hi)
@@ -509,17 +405,8 @@ __device__ __forceinline__ void st2(int *p, I2 v)
 	*reinterpret_cast<int2 *>(p) = make_int2(v.a, v.b);
 }
 
-__device__ __forceinline__ void st2(short *p, I2 v)
-{
-	*reinterpret_cast<unsigned *>(p) = ((unsigned)v.a & 0xffffu) | ((unsigned)v.b << 16);
-}
 
 // first sample of the plane's source and the channel a launch extracts (RGB only)
-__device__ __forceinline__ const int *fwd_base(SrcTag<int>, const LevelArgs &a, int plane, int &ch)
-{
-	ch = 0;
-	return a.src + plane * a.src_ps;
-}
 __device__ __forceinline__ const uint8_t *fwd_base(SrcTag<uint8_t>, const LevelArgs &a, int plane, int &ch)
 {
 	ch = 0;
@@ -577,134 +464,191 @@ struct IsRgb<Rgb8> {
 	static constexpr bool value = true;
 };
 
-template <typename SrcT, bool HIST>
+// A row moves from the registers it was loaded into to the registers it is used from: a move the register allocator
+// cannot fold away, placed where the wave is to wait for the row (see the loop of k_fwd_level_w).
+__device__ __forceinline__ unsigned hold(unsigned v)
+{
+	unsigned o;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
+	return o;
+}
+__device__ __forceinline__ int hold(int v) { return (int)hold((unsigned)v); }
+
+// One int32 row of the wave's strip as it is loaded: every lane loads — lanes beyond the row from the row's last quad,
+// the edge pair from a clamped place — so that no load sits behind a branch or feeds a select (either would make the
+// wave wait for it at once); what the extra lanes get is never used.
+struct FwdRawI {
+	int4 x;           // x[4q .. 4q+3]
+	int2 e;           // lane 0: x[4q-2], x[4q-1]; the other lanes: e.x = x[4q+4]
+};
+struct LaneAtI {
+	int main, edge;   // offsets in a row, in samples
+};
+
+__device__ __forceinline__ LaneAtI lane_at_i(int q, int lane, int nquads)
+{
+	const int qa = min(q, nquads - 1);
+	LaneAtI o = { 4 * qa, lane == 0 ? max(4 * qa - 2, 0) : min(4 * qa + 4, 4 * nquads - 2) };
+	return o;
+}
+
+__device__ __forceinline__ FwdRawI fwd_load_i(const int *__restrict__ row, const LaneAtI &at)
+{
+	FwdRawI r;
+	r.x = *reinterpret_cast<const int4 *>(row + at.main);
+	r.e = *reinterpret_cast<const int2 *>(row + at.edge);
+	return r;
+}
+
+__device__ __forceinline__ FwdRaw hold(const FwdRawI &r)
+{
+	FwdRaw o;
+	o.x = make_int4(hold(r.x.x), hold(r.x.y), hold(r.x.z), hold(r.x.w));
+	o.xr = hold(r.e.x);
+	o.left = make_int2(o.xr, hold(r.e.y));
+	return o;
+}
+
+// Forward level on int32 planes (every level of dwtx_transformation_fwd; the levels below the finest in the codec).
+// Memory operations retire in order on this part (one counter for loads and stores): a wave that waits for rows it
+// loaded also waits for everything it issued before them, and a wait the compiler cannot count exactly waits for
+// everything.  So the loop works in batches of S row pairs: wait once (where the rows are moved to the registers they
+// are used from), send the previous batch's results out, ask for the next batch's rows, then compute S row pairs
+// without touching memory — by the next wait both the stores and the loads are a whole batch of arithmetic old.
+template <bool HIST>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int bx, by, chan = 0;
-	if (IsRgb<SrcT>::value)
-		xcd_strip_rgb(bx, by, chan);
-	else
-		xcd_strip(bx, by);
+	int bx, by;
+	xcd_strip(bx, by);
 	const int sx = (bx << A.wx_log2) + (wv & ((1 << A.wx_log2) - 1));   // the wave's strip of 64 quads
 	const int q = sx * 64 + lane;
 	const int j0 = (by * (WAVES >> A.wx_log2) + (wv >> A.wx_log2)) * a.rpw;
 	if (j0 >= a.h2 || sx * 64 >= A.nquads)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
-	const int plane = IsRgb<SrcT>::value ? (int)blockIdx.z * 3 + chan : (int)blockIdx.z;
+	const int plane = blockIdx.z;
 	const bool valid = q < A.nquads;
-	int ch;
-	const typename SrcElem<SrcT>::type *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
+	const int *src = a.src + plane * a.src_ps;
 	int *ll = a.ll + plane * a.ll_ps;
 	int *det = a.det + plane * a.det_ps;
-	short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;   // (uniform)
 
-	int jj = j0 > 0 ? j0 - 1 : 0;
+	constexpr int S = 2;
+	const int jfirst = j0 > 0 ? j0 - 1 : 0;
+	const LaneAtI at = lane_at_i(q, lane, A.nquads);
 	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
-	typedef typename RawOf<SrcT>::type Raw;
 	{
-		const Raw r0 = fwd_load_w(SrcTag<SrcT>(), src + (long)(2 * jj) * a.spitch, q, lane, A.nquads, valid, ch);
-		fwd_lift_w(fwd_widen(r0, ch), q, lane, A.nquads, l0, h0);
+		const FwdRawI r0 = fwd_load_i(src + (long)(2 * jfirst) * a.spitch, at);
+		FwdRaw u;
+		u.x = r0.x;
+		u.xr = r0.e.x;
+		u.left = r0.e;
+		fwd_lift_w(u, q, lane, A.nquads, l0, h0);
 	}
-	// rows 2jj+1, 2jj+2 of the next two iterations are kept in flight: one wave alone cannot cover
-	// the HBM latency with a single row pair outstanding
 	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
-	Raw n1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 1), q, lane, A.nquads, valid, ch);
-	Raw n2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 2), q, lane, A.nquads, valid, ch);
-	Raw m1 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 3), q, lane, A.nquads, valid, ch);
-	Raw m2 = fwd_load_w(SrcTag<SrcT>(), rowp(2 * jj + 4), q, lane, A.nquads, valid, ch);
-	HistAcc hHL = { 0, 0, 0, 0 }, hLH = { 0, 0, 0, 0 }, hHH = { 0, 0, 0, 0 };
-	for (; jj < j1; ++jj) {
-		const int r1 = 2 * jj + 1, r2 = r1 + 1;
-		const bool odd_in = r1 < a.h;
-		const Raw c1 = n1, c2 = n2;
-		n1 = m1;
-		n2 = m2;
-		if (jj + 2 < j1) {
-			m1 = fwd_load_w(SrcTag<SrcT>(), rowp(r1 + 4), q, lane, A.nquads, valid, ch);
-			m2 = fwd_load_w(SrcTag<SrcT>(), rowp(r2 + 4), q, lane, A.nquads, valid, ch);
+	FwdRaw cur[2 * S];
+	FwdRawI nxt[2 * S];
+#pragma unroll
+	for (int k = 0; k < 2 * S; ++k)
+		nxt[k] = fwd_load_i(rowp(2 * jfirst + 1 + k), at);
+	I2 osl[S], osh[S], odl[S], odh[S];   // a batch's results wait here for the next iteration's stores
+	auto store_batch = [&](int jb) {
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int j = jb + s;
+			if (j >= j0 && j < j1 && valid) {
+				st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
+				st2(det + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
+				if (2 * j + 1 < a.h) {
+					st2(det + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
+					st2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+				}
+			}
 		}
-		I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
-		if (odd_in)
-			fwd_lift_w(fwd_widen(c1, ch), q, lane, A.nquads, l1, h1);
-		if (r2 < a.h)
-			fwd_lift_w(fwd_widen(c2, ch), q, lane, A.nquads, l2, h2v);
-		const I2 dl = i2_pred(l1, l0, l2);
-		const I2 dh = i2_pred(h1, h0, h2v);
-		if (jj >= j0 && valid) {
+	};
+	HistAcc hHL = { 0, 0, 0, 0 }, hLH = { 0, 0, 0, 0 }, hHH = { 0, 0, 0, 0 };
+	for (int jb = jfirst; jb < j1; jb += S) {
+#pragma unroll
+		for (int k = 0; k < 2 * S; ++k)
+			cur[k] = hold(nxt[k]);   // the one wait of the iteration: everything outstanding is a batch old
+		if (jb > jfirst)
+			store_batch(jb - S);
+		if (jb + S < j1) {
+#pragma unroll
+			for (int k = 0; k < 2 * S; ++k)
+				nxt[k] = fwd_load_i(rowp(2 * (jb + S) + 1 + k), at);
+		}
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int jj = jb + s;
+			if (jj >= j1)
+				break;
+			const int r1 = 2 * jj + 1, r2 = r1 + 1;
+			const bool odd_in = r1 < a.h;
+			I2 l1 = { 0, 0 }, h1 = { 0, 0 }, l2 = l0, h2v = h0;
+			if (odd_in)
+				fwd_lift_w(cur[2 * s], q, lane, A.nquads, l1, h1);
+			if (r2 < a.h)
+				fwd_lift_w(cur[2 * s + 1], q, lane, A.nquads, l2, h2v);
+			const I2 dl = i2_pred(l1, l0, l2);
+			const I2 dh = i2_pred(h1, h0, h2v);
 			I2 sl = l0, sh = h0;
 			if (odd_in) {
 				sl = i2_upd(l0, jj ? pl : dl, dl);
 				sh = i2_upd(h0, jj ? ph : dh, dh);
 			}
-			st2(ll + (long)jj * a.llpitch + 2 * q, sl);
-			if (det16) {
-				st2(det16 + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
-				if (odd_in) {
-					st2(det16 + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
-					st2(det16 + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+			osl[s] = sl;
+			osh[s] = sh;
+			odl[s] = dl;
+			odh[s] = dh;
+			if (HIST && jj >= j0) {
+				// the detail coefficients of this row pair (cdf53.h:9-34 output): HL row jj, LH and HH row h2 + jj
+				if (valid) {
+					hist_add(hHL, sh.a);
+					hist_add(hHL, sh.b);
+					if (odd_in) {
+						hist_add(hLH, dl.a);
+						hist_add(hLH, dl.b);
+						hist_add(hHH, dh.a);
+						hist_add(hHH, dh.b);
+					}
 				}
-			} else {
-				st2(det + (long)jj * a.dpitch + a.w2 + 2 * q, sh);
-				if (odd_in) {
-					st2(det + (long)(a.h2 + jj) * a.dpitch + 2 * q, dl);
-					st2(det + (long)(a.h2 + jj) * a.dpitch + a.w2 + 2 * q, dh);
+				if ((jj & 3) == 3) {   // eight coefficients per subband since the last fold: a nibble holds fifteen
+					hist_fold(hHL);
+					hist_fold(hLH);
+					hist_fold(hHH);
+				}
+				// a block ends where its 32 rows end (or the strip does): the rows of HL are jj, those of LH / HH h2 + jj
+				const bool last = jj == j1 - 1;
+				const int bxl = (2 * q) >> 5, bxh = (a.w2 + 2 * q) >> 5;
+				if (last || ((jj + 1) & 31) == 0)
+					hist_flush(hHL, A.hist, plane, bxh, jj >> 5, lane);
+				if (last || ((a.h2 + jj + 1) & 31) == 0) {
+					hist_flush(hLH, A.hist, plane, bxl, (a.h2 + jj) >> 5, lane);
+					hist_flush(hHH, A.hist, plane, bxh, (a.h2 + jj) >> 5, lane);
 				}
 			}
+			pl = dl;
+			ph = dh;
+			l0 = l2;
+			h0 = h2v;
 		}
-		if (HIST && jj >= j0) {
-			// the detail coefficients of this row pair, as they were stored (cdf53.h:9-34 output): HL row jj, LH and HH row h2 + jj
-			if (valid) {
-				const I2 sh = odd_in ? i2_upd(h0, jj ? ph : dh, dh) : h0;
-				hist_add(hHL, sh.a);
-				hist_add(hHL, sh.b);
-				if (odd_in) {
-					hist_add(hLH, dl.a);
-					hist_add(hLH, dl.b);
-					hist_add(hHH, dh.a);
-					hist_add(hHH, dh.b);
-				}
-			}
-			if ((jj & 3) == 3) {   // eight coefficients per subband since the last fold: a nibble holds fifteen
-				hist_fold(hHL);
-				hist_fold(hLH);
-				hist_fold(hHH);
-			}
-			// a block ends where its 32 rows end (or the strip does): the rows of HL are jj, those of LH / HH h2 + jj
-			const bool last = jj == j1 - 1;
-			const int bxl = (2 * q) >> 5, bxh = (a.w2 + 2 * q) >> 5;
-			if (last || ((jj + 1) & 31) == 0)
-				hist_flush(hHL, A.hist, plane, bxh, jj >> 5, lane);
-			if (last || ((a.h2 + jj + 1) & 31) == 0) {
-				hist_flush(hLH, A.hist, plane, bxl, (a.h2 + jj) >> 5, lane);
-				hist_flush(hHH, A.hist, plane, bxh, (a.h2 + jj) >> 5, lane);
-			}
-		}
-		pl = dl;
-		ph = dh;
-		l0 = l2;
-		h0 = h2v;
 	}
+	store_batch(jfirst + (j1 - 1 - jfirst) / S * S);   // the last batch (a strip has at least one row pair)
 }
 
 // ---- the finest level from 8-bit pixels, in packed 16-bit arithmetic ----
 // Samples of magnitude <= 255 cannot leave 16 bits anywhere in one level of cdf53.h:9-34 (|d| <= 510 after the row
 // pass, <= 1020 after the column pass; every intermediate sum stays below 2^12): the lane's two column pairs ride in
 // the halves of one register and every add / shift / subtract is a v_pk_* instruction on both.  Same results as
-// k_fwd_level_w<uint8_t / Rgb8>, which this replaces (about half its vector instructions).
+// the int32 arithmetic of k_fwd_level_w, with about half the vector instructions.
 typedef short P2 __attribute__((ext_vector_type(2)));
 typedef unsigned short U2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ P2 p2_of(unsigned u) { return __builtin_bit_cast(P2, u); }
 __device__ __forceinline__ unsigned bits_of(P2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ P2 tdiv2p(P2 a) { return (a + (P2)((U2)a >> (U2)15)) >> (P2)1; }
 __device__ __forceinline__ P2 tdiv4p(P2 a) { return (a + ((a >> (P2)15) & (P2)3)) >> (P2)2; }
-__device__ __forceinline__ I2 i2_of(P2 v)
-{
-	I2 r = { (int)v.x, (int)v.y };
-	return r;
-}
 
 // image.h:52-65 on two pixels at once: channel ch of (R, G, B) pairs
 __device__ __forceinline__ P2 ycocg_p(P2 r, P2 g, P2 b, int ch)
@@ -829,14 +773,6 @@ __device__ __forceinline__ FwdRawRgbP fwd_load_p(SrcTag<Rgb8>, const uint8_t *__
 	return r;
 }
 
-// a row moves from the registers it was loaded into to the registers it is used from: a move the register allocator
-// cannot fold away, placed where the wave is to wait for the row
-__device__ __forceinline__ unsigned hold(unsigned v)
-{
-	unsigned o;
-	asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(v));
-	return o;
-}
 __device__ __forceinline__ FwdRaw8 hold(const FwdRaw8 &r)
 {
 	FwdRaw8 o = { hold(r.v), hold(r.edge) };
@@ -1007,8 +943,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
 	store_batch(jfirst + (j1 - 1 - jfirst) / S * S);
 }
 
-// LL | HL | LH | HH samples of one row pair as they were loaded (F16: the detail bands are words of two 16-bit values;
-// they are widened when used — anything computed at load time would make the wave wait for the load right there)
+// ---------------------------------------------------------------- inverse ---
+// LL | HL | LH | HH samples of one row pair as they are loaded (F16: the detail bands are words of two 16-bit values,
+// widened when used).  Every lane loads — lanes outside the row from a clamped quad, row pairs beyond the band from
+// the last one — so that no load sits behind a branch or feeds a select; what those get is never used.
 template <bool F16>
 struct InvRawT {
 	int2 sl, sh, dl, dh;
@@ -1021,35 +959,50 @@ struct InvRawT<true> {
 
 __device__ __forceinline__ int2 ld2(const int *p) { return *reinterpret_cast<const int2 *>(p); }
 
-__device__ __forceinline__ InvRawT<false> inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, int qd, bool valid)
+// where a lane reads: its (clamped) column pair, and the clamps for the row pair index
+struct InvAt {
+	int col;          // 2 * clamped quad
+	int jmax, jdmax;  // last row pair of the LL / HL bands, last of the LH / HH bands (an odd height has one row less there)
+};
+
+__device__ __forceinline__ InvAt inv_at(const LevelArgs &a, int qd, int nquads)
+{
+	InvAt o = { 2 * min(max(qd, 0), nquads - 1), a.h2 - 1, a.h / 2 - 1 };
+	return o;
+}
+
+__device__ __forceinline__ InvRawT<false> inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, const InvAt &at)
 {
 	InvRawT<false> r;
-	r.sl = r.sh = r.dl = r.dh = make_int2(0, 0);
-	if (valid && j < a.h2) {
-		r.sl = ld2(llp + (long)j * a.spitch + 2 * qd);
-		r.sh = ld2(det + (long)j * a.dpitch + a.w2 + 2 * qd);
-		if (2 * j + 1 < a.h) {
-			r.dl = ld2(det + (long)(a.h2 + j) * a.dpitch + 2 * qd);
-			r.dh = ld2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
-		}
-	}
+	const int ja = min(j, at.jmax), jd = min(j, at.jdmax);
+	r.sl = ld2(llp + (long)ja * a.spitch + at.col);
+	r.sh = ld2(det + (long)ja * a.dpitch + a.w2 + at.col);
+	r.dl = ld2(det + (long)(a.h2 + jd) * a.dpitch + at.col);
+	r.dh = ld2(det + (long)(a.h2 + jd) * a.dpitch + a.w2 + at.col);
 	return r;
 }
 
-__device__ __forceinline__ InvRawT<true> inv_load_w(const LevelArgs &a, const int *llp, const short *det16, int j, int qd, bool valid)
+__device__ __forceinline__ InvRawT<true> inv_load_w(const LevelArgs &a, const int *llp, const short *det16, int j, const InvAt &at)
 {
 	InvRawT<true> r;
-	r.sl = make_int2(0, 0);
-	r.sh = r.dl = r.dh = 0u;
-	if (valid && j < a.h2) {
-		r.sl = ld2(llp + (long)j * a.spitch + 2 * qd);
-		r.sh = *reinterpret_cast<const unsigned *>(det16 + (long)j * a.dpitch + a.w2 + 2 * qd);
-		if (2 * j + 1 < a.h) {
-			r.dl = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + j) * a.dpitch + 2 * qd);
-			r.dh = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * qd);
-		}
-	}
+	const int ja = min(j, at.jmax), jd = min(j, at.jdmax);
+	r.sl = ld2(llp + (long)ja * a.spitch + at.col);
+	r.sh = *reinterpret_cast<const unsigned *>(det16 + (long)ja * a.dpitch + a.w2 + at.col);
+	r.dl = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + jd) * a.dpitch + at.col);
+	r.dh = *reinterpret_cast<const unsigned *>(det16 + (long)(a.h2 + jd) * a.dpitch + a.w2 + at.col);
 	return r;
+}
+
+__device__ __forceinline__ int2 hold(int2 v) { return make_int2(hold(v.x), hold(v.y)); }
+__device__ __forceinline__ InvRawT<false> hold(const InvRawT<false> &r)
+{
+	InvRawT<false> o = { hold(r.sl), hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
+}
+__device__ __forceinline__ InvRawT<true> hold(const InvRawT<true> &r)
+{
+	InvRawT<true> o = { hold(r.sl), hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
 }
 
 __device__ __forceinline__ I2 to_i2(int2 v)
@@ -1076,112 +1029,7 @@ struct DetPtr<true> {
 	static __device__ __forceinline__ type of(const LevelArgs &a, long plane) { return a.det16 + plane * a.det_ps; }
 };
 
-// horizontal inverse of one output row for this lane's two pairs
-__device__ __forceinline__ void inv_store_w(int *__restrict__ row, int qd, int e0, int o0, int e1, int o1)
-{
-	*reinterpret_cast<int4 *>(row + 4 * qd) = make_int4(e0, o0, e1, o1);
-}
-
-__device__ __forceinline__ void inv_store_w(uint8_t *__restrict__ row, int qd, int e0, int o0, int e1, int o1)
-{
-	auto c8 = [](int v) { return (unsigned)(v < 0 ? 0 : v > 255 ? 255 : v); };
-	*reinterpret_cast<unsigned *>(row + 4 * qd) = c8(e0) | (c8(o0) << 8) | (c8(e1) << 16) | (c8(o1) << 24);
-}
-
-template <typename DstT>
-__device__ __forceinline__ void inv_row_w(DstT *__restrict__ row, int qd, int nquads, bool writes, I2 lo, I2 hi)
-{
-	int hl = __shfl_up(hi.b, 1);
-	if (qd <= 0)
-		hl = hi.a;
-	const int e0 = lo.a - tdiv4(hl + hi.a);
-	const int e1 = lo.b - tdiv4(hi.a + hi.b);
-	int er = __shfl_down(e0, 1);
-	if (qd + 1 >= nquads)
-		er = e1;
-	const int o0 = hi.a + tdiv2(e0 + e1);
-	const int o1 = hi.b + tdiv2(e1 + er);
-	if (writes)
-		inv_store_w(row, qd, e0, o0, e1, o1);
-}
-
-template <typename DstT>
-__device__ __forceinline__ DstT *inv_dst(const LevelArgs &a);
-template <>
-__device__ __forceinline__ int *inv_dst<int>(const LevelArgs &a) { return a.ll; }
-template <>
-__device__ __forceinline__ uint8_t *inv_dst<uint8_t>(const LevelArgs &a) { return a.dst8; }
-
-template <typename DstT, bool F16>
-__global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
-{
-	const LevelArgs &a = A.a;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int bx, by;
-	xcd_strip(bx, by);
-	const int qd = bx * INV_QUADS - 1 + lane;
-	const int j0 = (by * WAVES + wv) * a.rpw;
-	if (j0 >= a.h2)
-		return;
-	const int j1 = min(j0 + a.rpw, a.h2);
-	const int plane = blockIdx.z;
-	const bool valid = qd >= 0 && qd < A.nquads;
-	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
-	const int *llp = a.src + plane * a.src_ps;
-	const typename DetPtr<F16>::type det = DetPtr<F16>::of(a, plane);
-	typedef InvRawT<F16> InvRaw;
-	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
-	const bool h_odd = a.h & 1;
-
-	auto even_of = [&](int j, I2 s, I2 dprev, I2 dcur) {
-		if (h_odd && 2 * j == a.h - 1)
-			return s;
-		const I2 dp = j ? dprev : dcur;
-		I2 r = { s.a - tdiv4(dp.a + dcur.a), s.b - tdiv4(dp.b + dcur.b) };
-		return r;
-	};
-
-	I2 pdl = { 0, 0 }, pdh = { 0, 0 };
-	if (j0 > 0) {
-		const InvRaw p = inv_load_w(a, llp, det, j0 - 1, qd, valid);
-		pdl = to_i2(p.dl);
-		pdh = to_i2(p.dh);
-	}
-	// the subband rows of the next two row pairs are kept in flight (see k_fwd_level_w)
-	InvRaw cur = inv_load_w(a, llp, det, j0, qd, valid);
-	InvRaw nxt = inv_load_w(a, llp, det, j0 + 1, qd, valid);
-	InvRaw nx2 = inv_load_w(a, llp, det, j0 + 2, qd, valid);
-	I2 dl = to_i2(cur.dl), dh = to_i2(cur.dh);
-	I2 el = even_of(j0, to_i2(cur.sl), pdl, dl), eh = even_of(j0, to_i2(cur.sh), pdh, dh);
-	for (int jj = j0; jj < j1; ++jj) {
-		const int r0 = 2 * jj, r1 = r0 + 1;
-		const InvRaw n = nxt;
-		nxt = nx2;
-		if (jj + 2 < j1)
-			nx2 = inv_load_w(a, llp, det, jj + 3, qd, valid);
-		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el, neh = eh;   // mirror x[h] := x[h-2]
-		if (r1 + 1 < a.h) {
-			ndl = to_i2(n.dl);
-			ndh = to_i2(n.dh);
-			nel = even_of(jj + 1, to_i2(n.sl), dl, ndl);
-			neh = even_of(jj + 1, to_i2(n.sh), dh, ndh);
-		}
-		inv_row_w(dst + (long)r0 * a.llpitch, qd, A.nquads, writes, el, eh);
-		if (r1 < a.h) {
-			const I2 ol = { dl.a + tdiv2(el.a + nel.a), dl.b + tdiv2(el.b + nel.b) };
-			const I2 oh = { dh.a + tdiv2(eh.a + neh.a), dh.b + tdiv2(eh.b + neh.b) };
-			inv_row_w(dst + (long)r1 * a.llpitch, qd, A.nquads, writes, ol, oh);
-		}
-		dl = ndl;
-		dh = ndh;
-		el = nel;
-		eh = neh;
-	}
-}
-
-// The finest inverse level of an RGB image: one wave carries the same columns of the three planes
-// (Y, Co, Cg) and writes interleaved 8-bit pixels — image.h:39-50 ycocg2rgb with its input clamps and
-// the output clamp of pnm.h:108 fused in.  grid.z = image; dst8 rows are 3*w bytes.
+// horizontal inverse of one output row for this lane's two pairs: x[4qd .. 4qd+3]
 struct Quad4 {
 	int v[4];
 };
@@ -1204,12 +1052,167 @@ __device__ __forceinline__ Quad4 inv_row_vals(int qd, int nquads, I2 lo, I2 hi)
 	return r;
 }
 
+// a finished output row in the registers it waits in for its store: four int32 samples, or four clamped 8-bit pixels (pnm.h:108)
+template <typename DstT>
+struct OutRow {
+	typedef int4 type;
+	static __device__ __forceinline__ type of(const Quad4 &v) { return make_int4(v.v[0], v.v[1], v.v[2], v.v[3]); }
+	static __device__ __forceinline__ void store(int *__restrict__ row, int qd, const type &v) { *reinterpret_cast<int4 *>(row + 4 * qd) = v; }
+};
+template <>
+struct OutRow<uint8_t> {
+	typedef unsigned type;
+	static __device__ __forceinline__ type of(const Quad4 &v)
+	{
+		auto c8 = [](int x) { return (unsigned)(x < 0 ? 0 : x > 255 ? 255 : x); };
+		return c8(v.v[0]) | (c8(v.v[1]) << 8) | (c8(v.v[2]) << 16) | (c8(v.v[3]) << 24);
+	}
+	static __device__ __forceinline__ void store(uint8_t *__restrict__ row, int qd, const type &v) { *reinterpret_cast<unsigned *>(row + 4 * qd) = v; }
+};
+
+template <typename DstT>
+__device__ __forceinline__ DstT *inv_dst(const LevelArgs &a);
+template <>
+__device__ __forceinline__ int *inv_dst<int>(const LevelArgs &a) { return a.ll; }
+template <>
+__device__ __forceinline__ uint8_t *inv_dst<uint8_t>(const LevelArgs &a) { return a.dst8; }
+
+// The vertical state of one plane between row pairs: detail rows dl / dh and even rows el / eh of the current pair.
+struct InvCols {
+	I2 dl, dh, el, eh;
+};
+
+// cdf53.h:40-47 down the columns: the even row of pair j from its subband samples and the details around it
+__device__ __forceinline__ I2 inv_even(const LevelArgs &a, int j, I2 s, I2 dprev, I2 dcur)
+{
+	if ((a.h & 1) && 2 * j == a.h - 1)
+		return s;
+	const I2 dp = j ? dprev : dcur;
+	I2 r = { s.a - tdiv4(dp.a + dcur.a), s.b - tdiv4(dp.b + dcur.b) };
+	return r;
+}
+
+// the strip's first row pair: what the loop carries
+template <class Raw>
+__device__ __forceinline__ InvCols inv_first(const LevelArgs &a, int j0, const Raw &before, const Raw &first)
+{
+	I2 pdl = { 0, 0 }, pdh = { 0, 0 };
+	if (j0 > 0) {
+		pdl = to_i2(before.dl);
+		pdh = to_i2(before.dh);
+	}
+	InvCols c;
+	c.dl = to_i2(first.dl);
+	c.dh = to_i2(first.dh);
+	c.el = inv_even(a, j0, to_i2(first.sl), pdl, c.dl);
+	c.eh = inv_even(a, j0, to_i2(first.sh), pdh, c.dh);
+	return c;
+}
+
+// one row pair: its two output rows (the odd one only if it exists) from the state and the next pair's samples `n`
+template <class Raw>
+__device__ __forceinline__ void inv_pair(const LevelArgs &a, int jj, int qd, int nquads, InvCols &c, const Raw &n, Quad4 &even, Quad4 &odd)
+{
+	const int r1 = 2 * jj + 1;
+	I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = c.el, neh = c.eh;   // mirror x[h] := x[h-2]
+	if (r1 + 1 < a.h) {
+		if (r1 + 2 < a.h) {
+			ndl = to_i2(n.dl);
+			ndh = to_i2(n.dh);
+		}
+		nel = inv_even(a, jj + 1, to_i2(n.sl), c.dl, ndl);
+		neh = inv_even(a, jj + 1, to_i2(n.sh), c.dh, ndh);
+	}
+	even = inv_row_vals(qd, nquads, c.el, c.eh);
+	const I2 ol = { c.dl.a + tdiv2(c.el.a + nel.a), c.dl.b + tdiv2(c.el.b + nel.b) };   // cdf53.h:49-56
+	const I2 oh = { c.dh.a + tdiv2(c.eh.a + neh.a), c.dh.b + tdiv2(c.eh.b + neh.b) };
+	odd = inv_row_vals(qd, nquads, ol, oh);
+	c.dl = ndl;
+	c.dh = ndh;
+	c.el = nel;
+	c.eh = neh;
+}
+
+// Inverse level: int32 planes, or — the finest level of a gray image — clamped 8-bit pixels out (and, F16, the detail
+// bands in as 16-bit values).  The loop is batched like the forward kernel's (see there): one wait per S row pairs.
+template <typename DstT, bool F16>
+__global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
+{
+	const LevelArgs &a = A.a;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int qd = bx * INV_QUADS - 1 + lane;
+	const int j0 = (by * WAVES + wv) * a.rpw;
+	if (j0 >= a.h2)
+		return;
+	const int j1 = min(j0 + a.rpw, a.h2);
+	const int plane = blockIdx.z;
+	const bool valid = qd >= 0 && qd < A.nquads;
+	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
+	const int *llp = a.src + plane * a.src_ps;
+	const typename DetPtr<F16>::type det = DetPtr<F16>::of(a, plane);
+	typedef InvRawT<F16> InvRaw;
+	typedef OutRow<DstT> Out;
+	DstT *dst = inv_dst<DstT>(a) + plane * a.ll_ps;
+	const InvAt at = inv_at(a, qd, A.nquads);
+
+	constexpr int S = 2;
+	InvCols c = inv_first(a, j0, inv_load_w(a, llp, det, j0 > 0 ? j0 - 1 : 0, at), inv_load_w(a, llp, det, j0, at));
+	InvRaw nxt[S], cur[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s)
+		nxt[s] = inv_load_w(a, llp, det, j0 + 1 + s, at);
+	typename Out::type orow[2 * S];   // a batch's rows wait here for the next iteration's stores
+	auto store_batch = [&](int jb) {
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int j = jb + s;
+			if (j < j1 && writes) {
+				Out::store(dst + (long)(2 * j) * a.llpitch, qd, orow[2 * s]);
+				if (2 * j + 1 < a.h)
+					Out::store(dst + (long)(2 * j + 1) * a.llpitch, qd, orow[2 * s + 1]);
+			}
+		}
+	};
+	for (int jb = j0; jb < j1; jb += S) {
+#pragma unroll
+		for (int s = 0; s < S; ++s)
+			cur[s] = hold(nxt[s]);   // the one wait of the iteration
+		if (jb > j0)
+			store_batch(jb - S);
+		if (jb + S < j1) {
+#pragma unroll
+			for (int s = 0; s < S; ++s)
+				nxt[s] = inv_load_w(a, llp, det, jb + S + 1 + s, at);
+		}
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int jj = jb + s;
+			if (jj >= j1)
+				break;
+			Quad4 even, odd;
+			inv_pair(a, jj, qd, A.nquads, c, cur[s], even, odd);
+			orow[2 * s] = Out::of(even);
+			orow[2 * s + 1] = Out::of(odd);
+		}
+	}
+	store_batch(j0 + (j1 - 1 - j0) / S * S);
+}
+
+// The finest inverse level of an RGB image: one wave carries the same columns of the three planes
+// (Y, Co, Cg) and writes interleaved 8-bit pixels — image.h:39-50 ycocg2rgb with its input clamps and
+// the output clamp of pnm.h:108 fused in.  grid.z = image; dst8 rows are 3*w bytes.
 __device__ __forceinline__ int clamp_to(int v, int lo, int hi)
 {
 	return v < lo ? lo : v > hi ? hi : v;
 }
 
-__device__ __forceinline__ void rgb_store_w(uint8_t *__restrict__ row, int qd, const Quad4 &y, const Quad4 &co, const Quad4 &cg)
+struct Rgb12 {
+	unsigned w[3];   // four pixels
+};
+
+__device__ __forceinline__ Rgb12 rgb_of(const Quad4 &y, const Quad4 &co, const Quad4 &cg)
 {
 	unsigned char px[12];
 #pragma unroll
@@ -1223,10 +1226,11 @@ __device__ __forceinline__ void rgb_store_w(uint8_t *__restrict__ row, int qd, c
 		px[3 * k + 1] = (unsigned char)clamp_to(g, 0, 255);
 		px[3 * k + 2] = (unsigned char)clamp_to(b, 0, 255);
 	}
-	unsigned *w = reinterpret_cast<unsigned *>(row + 12 * qd);
+	Rgb12 o;
 #pragma unroll
 	for (int k = 0; k < 3; ++k)
-		w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+		o.w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+	return o;
 }
 
 template <bool F16>
@@ -1248,68 +1252,55 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	typename DetPtr<F16>::type det[3];
 	typedef InvRawT<F16> InvRaw;
 #pragma unroll
-	for (int c = 0; c < 3; ++c) {
-		llp[c] = a.src + (long)(3 * image + c) * a.src_ps;
-		det[c] = DetPtr<F16>::of(a, 3 * image + c);
+	for (int ch = 0; ch < 3; ++ch) {
+		llp[ch] = a.src + (long)(3 * image + ch) * a.src_ps;
+		det[ch] = DetPtr<F16>::of(a, 3 * image + ch);
 	}
 	uint8_t *dst = a.dst8 + image * a.ll_ps;
-	const bool h_odd = a.h & 1;
+	const InvAt at = inv_at(a, qd, A.nquads);
 
-	auto even_of = [&](int j, I2 s, I2 dprev, I2 dcur) {
-		if (h_odd && 2 * j == a.h - 1)
-			return s;
-		const I2 dp = j ? dprev : dcur;
-		I2 r = { s.a - tdiv4(dp.a + dcur.a), s.b - tdiv4(dp.b + dcur.b) };
-		return r;
-	};
-
-	I2 dl[3], dh[3], el[3], eh[3];
-	InvRaw nxt[3];
+	// (one row pair per batch: three planes' worth of arithmetic lies between two waits as it is)
+	InvCols c[3];
+	InvRaw nxt[3], cur[3];
 #pragma unroll
-	for (int c = 0; c < 3; ++c) {
-		I2 pdl = { 0, 0 }, pdh = { 0, 0 };
-		if (j0 > 0) {
-			const InvRaw p = inv_load_w(a, llp[c], det[c], j0 - 1, qd, valid);
-			pdl = to_i2(p.dl);
-			pdh = to_i2(p.dh);
-		}
-		const InvRaw cur = inv_load_w(a, llp[c], det[c], j0, qd, valid);
-		nxt[c] = inv_load_w(a, llp[c], det[c], j0 + 1, qd, valid);
-		dl[c] = to_i2(cur.dl);
-		dh[c] = to_i2(cur.dh);
-		el[c] = even_of(j0, to_i2(cur.sl), pdl, dl[c]);
-		eh[c] = even_of(j0, to_i2(cur.sh), pdh, dh[c]);
+	for (int ch = 0; ch < 3; ++ch) {
+		c[ch] = inv_first(a, j0, inv_load_w(a, llp[ch], det[ch], j0 > 0 ? j0 - 1 : 0, at), inv_load_w(a, llp[ch], det[ch], j0, at));
+		nxt[ch] = inv_load_w(a, llp[ch], det[ch], j0 + 1, at);
 	}
+	Rgb12 orow[2];
+	auto store_pair = [&](int j) {
+		if (writes) {
+			unsigned *w0 = reinterpret_cast<unsigned *>(dst + (long)(2 * j) * a.llpitch + 12 * qd);
+			w0[0] = orow[0].w[0];
+			w0[1] = orow[0].w[1];
+			w0[2] = orow[0].w[2];
+			if (2 * j + 1 < a.h) {
+				unsigned *w1 = reinterpret_cast<unsigned *>(dst + (long)(2 * j + 1) * a.llpitch + 12 * qd);
+				w1[0] = orow[1].w[0];
+				w1[1] = orow[1].w[1];
+				w1[2] = orow[1].w[2];
+			}
+		}
+	};
 	for (int jj = j0; jj < j1; ++jj) {
-		const int r0 = 2 * jj, r1 = r0 + 1;
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch)
+			cur[ch] = hold(nxt[ch]);   // the one wait of the iteration
+		if (jj > j0)
+			store_pair(jj - 1);
+		if (jj + 1 < j1) {
+#pragma unroll
+			for (int ch = 0; ch < 3; ++ch)
+				nxt[ch] = inv_load_w(a, llp[ch], det[ch], jj + 2, at);
+		}
 		Quad4 even[3], odd[3];
 #pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			const InvRaw n = nxt[c];
-			if (jj + 1 < j1)
-				nxt[c] = inv_load_w(a, llp[c], det[c], jj + 2, qd, valid);   // three planes in flight: one row pair ahead each
-			I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = el[c], neh = eh[c];     // mirror x[h] := x[h-2]
-			if (r1 + 1 < a.h) {
-				ndl = to_i2(n.dl);
-				ndh = to_i2(n.dh);
-				nel = even_of(jj + 1, to_i2(n.sl), dl[c], ndl);
-				neh = even_of(jj + 1, to_i2(n.sh), dh[c], ndh);
-			}
-			even[c] = inv_row_vals(qd, A.nquads, el[c], eh[c]);
-			const I2 ol = { dl[c].a + tdiv2(el[c].a + nel.a), dl[c].b + tdiv2(el[c].b + nel.b) };
-			const I2 oh = { dh[c].a + tdiv2(eh[c].a + neh.a), dh[c].b + tdiv2(eh[c].b + neh.b) };
-			odd[c] = inv_row_vals(qd, A.nquads, ol, oh);
-			dl[c] = ndl;
-			dh[c] = ndh;
-			el[c] = nel;
-			eh[c] = neh;
-		}
-		if (writes) {
-			rgb_store_w(dst + (long)r0 * a.llpitch, qd, even[0], even[1], even[2]);
-			if (r1 < a.h)
-				rgb_store_w(dst + (long)r1 * a.llpitch, qd, odd[0], odd[1], odd[2]);
-		}
+		for (int ch = 0; ch < 3; ++ch)
+			inv_pair(a, jj, qd, A.nquads, c[ch], cur[ch], even[ch], odd[ch]);
+		orow[0] = rgb_of(even[0], even[1], even[2]);
+		orow[1] = rgb_of(odd[0], odd[1], odd[2]);
 	}
+	store_pair(j1 - 1);
 }
 
 // ------------------------------------------------------------ coarse tail ---
@@ -1739,13 +1730,13 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 				else if (bytes_in)
 					hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else
-					hipLaunchKernelGGL((k_fwd_level_w<int, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+					hipLaunchKernelGGL(k_fwd_level_w<true>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			} else if (bytes_in && in8_channels == 3)
 				hipLaunchKernelGGL((k_fwd_pixels_w<Rgb8, false>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_in)
 				hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
-				hipLaunchKernelGGL((k_fwd_level_w<int, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL(k_fwd_level_w<false>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, 64);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);
