@@ -1269,17 +1269,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	}
 	Rgb12 orow[2];
 	auto store_pair = [&](int j) {
-		if (writes) {
-			unsigned *w0 = reinterpret_cast<unsigned *>(dst + (long)(2 * j) * a.llpitch + 12 * qd);
-			w0[0] = orow[0].w[0];
-			w0[1] = orow[0].w[1];
-			w0[2] = orow[0].w[2];
-			if (2 * j + 1 < a.h) {
-				unsigned *w1 = reinterpret_cast<unsigned *>(dst + (long)(2 * j + 1) * a.llpitch + 12 * qd);
-				w1[0] = orow[1].w[0];
-				w1[1] = orow[1].w[1];
-				w1[2] = orow[1].w[2];
-			}
+		if (writes) {   // twelve bytes per lane in one store: the wave's 56 lanes write 672 consecutive bytes
+			U32x3 v0 = { orow[0].w[0], orow[0].w[1], orow[0].w[2] }, v1 = { orow[1].w[0], orow[1].w[1], orow[1].w[2] };
+			*reinterpret_cast<U32x3 *>(dst + (long)(2 * j) * a.llpitch + 12 * qd) = v0;
+			if (2 * j + 1 < a.h)
+				*reinterpret_cast<U32x3 *>(dst + (long)(2 * j + 1) * a.llpitch + 12 * qd) = v1;
 		}
 	};
 	for (int jj = j0; jj < j1; ++jj) {
