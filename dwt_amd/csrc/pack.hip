@@ -1508,6 +1508,22 @@ constexpr unsigned VOID2 = (T_VOID | T_NOSIGN) * 0x00010001u;
 
 __device__ __forceinline__ void stage_tokens(unsigned *rows, const unsigned short *tok16, long t0, long T, int lane)
 {
+	if (t0 >= 0 && t0 + CHUNK <= T) {
+		// the whole window holds tokens (all but an image's first and last window): eight loads that feed nothing but
+		// their LDS stores — no select on what they return, so they are all on their way before the first is waited for
+		uint4 v[8];
+#pragma unroll
+		for (int it = 0; it < 8; ++it)
+			v[it] = *reinterpret_cast<const uint4 *>(tok16 + t0 + it * 512 + lane * 8);
+#pragma unroll
+		for (int it = 0; it < 8; ++it) {
+			const int off = it * 512 + lane * 8;
+			unsigned *dst = rows + (off >> 6) * WROW + ((off & 63) >> 1);
+			*reinterpret_cast<uint2 *>(dst) = make_uint2(v[it].x, v[it].y);
+			*reinterpret_cast<uint2 *>(dst + 2) = make_uint2(v[it].z, v[it].w);
+		}
+		return;
+	}
 #pragma unroll
 	for (int it = 0; it < 8; ++it) {
 		const int off = it * 512 + lane * 8;
@@ -1533,8 +1549,20 @@ __device__ __forceinline__ void stage_tokens(unsigned *rows, const unsigned shor
 // over 32 lanes).  k_emit walks its tokens once, front to back: staging them half by half halves its LDS.
 constexpr int HROW = 18;
 
-__device__ __forceinline__ void stage_tokens_half(unsigned *rows, const unsigned short *tok16, long t0, long T, int lane, int half)
+// the loads of one half (in registers: the second half's are asked for before the first half is walked) ...
+struct HalfTokens {
+	uint4 v[4];
+};
+
+__device__ __forceinline__ HalfTokens load_tokens_half(const unsigned short *tok16, long t0, long T, int lane, int half)
 {
+	HalfTokens o;
+	if (t0 >= 0 && t0 + CHUNK <= T) {   // (uniform) the whole window holds tokens: plain loads, nothing selected from what they return
+#pragma unroll
+		for (int it = 0; it < 4; ++it)
+			o.v[it] = *reinterpret_cast<const uint4 *>(tok16 + t0 + (it * 16 + (lane >> 2)) * 64 + half * 32 + (lane & 3) * 8);
+		return o;
+	}
 #pragma unroll
 	for (int it = 0; it < 4; ++it) {
 		const int grp = it * 16 + (lane >> 2), piece = lane & 3;   // 16 bytes = 8 tokens per lane
@@ -1549,9 +1577,20 @@ __device__ __forceinline__ void stage_tokens_half(unsigned *rows, const unsigned
 				h[e] = t + e >= 0 && t + e < T ? (unsigned)tok16[t + e] : (T_VOID | T_NOSIGN);
 			v = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
 		}
+		o.v[it] = v;
+	}
+	return o;
+}
+
+// ... and their places in the rows
+__device__ __forceinline__ void deposit_tokens_half(unsigned *rows, const HalfTokens &h, int lane)
+{
+#pragma unroll
+	for (int it = 0; it < 4; ++it) {
+		const int grp = it * 16 + (lane >> 2), piece = lane & 3;
 		unsigned *dst = rows + grp * HROW + piece * 4;
-		*reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
-		*reinterpret_cast<uint2 *>(dst + 2) = make_uint2(v.z, v.w);
+		*reinterpret_cast<uint2 *>(dst) = make_uint2(h.v[it].x, h.v[it].y);
+		*reinterpret_cast<uint2 *>(dst + 2) = make_uint2(h.v[it].z, h.v[it].w);
 	}
 }
 
@@ -2059,10 +2098,13 @@ __global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_wo
 		len = vd ? 0 : l;
 		o = vd ? o : (top >= 2 ? top - 2 : 0);
 	};
+	HalfTokens staged = load_tokens_half(tok16, wave * CHUNK, T, lane, 0);
 	for (int half = 0; half < 2; ++half) {   // (uniform: every lane of the wave takes part in the staging)
 		if (half)
 			wave_sync();   // the first half's rows have been read
-		stage_tokens_half(rows, tok16, wave * CHUNK, T, lane, half);
+		deposit_tokens_half(rows, staged, lane);
+		if (!half)
+			staged = load_tokens_half(tok16, wave * CHUNK, T, lane, 1);   // on its way while the first half is walked
 		wave_sync();
 		if (!live)
 			continue;
