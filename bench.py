@@ -460,7 +460,7 @@ def main():
             for key in ("per_kernel", "planes"):
                 if key in tj:
                     traffic_detail[key] = tj[key]
-            # the finest level's u8 kernels as the codec runs them (pixels in, int32 subbands out and back): 5 B per sample
+            # the finest level's u8 kernels as the codec runs them (pixels in; LL as int32, the detail bands as int16 out and back): 3.5 B per sample
             u8path = os.path.join(ROOT, "profiles", "r03_lift8_traffic_pmc.json")
             if os.path.exists(u8path):
                 traffic_detail["u8_finest_level_kernels"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r03_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")

@@ -54,6 +54,29 @@ def test_random_int_planes_batch(ctx, shape):
     assert (inv_got.cpu().numpy() == inv_want).all()
 
 
+@pytest.mark.parametrize("shape", [(200, 4), (333, 8), (131, 12), (65, 256), (66, 260), (67, 516), (257, 1028), (1030, 68), (2050, 72), (3, 128), (2, 512)])
+def test_wide_kernels_at_their_edges(ctx, shape):
+    """The 16-byte-per-lane kernels work in batches of two row pairs with loads from clamped places (lift.hip): one quad
+    per row, one lane past a full strip, odd heights (the last row pair has no odd row), strips that end inside a batch,
+    heights of two and three rows.  int32 planes both ways against the oracle, and 8-bit pixels through the codec."""
+    import torch
+
+    H, W = shape
+    rng = np.random.default_rng(H * 7 + W)
+    a = rng.integers(-3000, 3000, size=(3, H, W), dtype=np.int32)
+    want = np.stack([orc.forward(a[p][:, :, None])[:, :, 0] for p in range(3)])
+    pyr = ctx.transformation_fwd(torch.from_numpy(a).cuda())
+    assert (pyr.cpu().numpy() == want).all()
+    inv_want = np.stack([orc.inverse(a[p][:, :, None])[:, :, 0] for p in range(3)])
+    assert (ctx.transformation_inv(torch.from_numpy(a).cuda()).cpu().numpy() == inv_want).all()
+    if H >= 8 and W >= 8:
+        for Cn in (1, 3):
+            pix = np.stack([orc.synth(W, H, Cn, 11, 1), (rng.integers(0, 2, (H, W, Cn)) * 255).astype(np.uint8)])
+            streams, _ = ctx.encode(pix)
+            assert streams == [orc.encode(x)[0] for x in pix]
+            assert all((o == x).all() for o, x in zip(ctx.decode(streams), pix))
+
+
 def test_4096_gray_roundtrip_and_checksum(ctx):
     """BASELINE config B size: round trip + checksum against the oracle's pyramid."""
     import torch
