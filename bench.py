@@ -285,8 +285,8 @@ def golden_check(name, stream0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gray4096", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default per workload)")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed on the CPU reference (0 = skip)")
