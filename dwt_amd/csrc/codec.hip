@@ -40,11 +40,11 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 	// The finest ring — three quarters of all coefficients — as 16-bit values in planes of its own when the transform
 	// starts from 8-bit pixels (no coefficient of that ring can leave 11 bits then) and the coder reads its squares in
 	// place: the transform writes, and the coder reads, half the bytes for it.
-	int16_t *fine16 = nullptr;
+	dwtx_p16 fine16 = { nullptr, 0u };
 	const bool from_pixels = dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C);
-	if (from_pixels && sq && !ctx->opt[DWTX_OPT_NO_FINE16] && dwtx_fine16_ok(W, H, sq)) {
-		fine16 = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
-		if (!fine16)
+	if (from_pixels && sq && !ctx->opt[DWTX_OPT_NO_FINE16] && (fine16.levels = dwtx_levels16(W, H, sq, 1))) {
+		fine16.planes = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
+		if (!fine16.planes)
 			return DWTX_ERR_NOMEM;
 	}
 	if (from_pixels) {
@@ -126,12 +126,14 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		return DWTX_ERR_NOMEM;
 	const size_t plane_ints = (size_t)W * H;
 	// 16-bit planes for the finest ring of whole pictures (see encode_part; the decoder checks the streams' plane counts)
-	int16_t *fine16 = nullptr;
+	// (every ring the 16-byte-per-lane inverse kernels take, up to five levels: what a stream holds is bounded by its
+	// plane counts on every level; the LL bands between the levels are sums of those and stay int32)
+	dwtx_p16 fine16 = { nullptr, 0u };
 	{
 		const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
-		if (sq && !ctx->opt[DWTX_OPT_NO_FINE16] && dwtx_fine16_ok(W, H, sq) && dwtx_gray8_ok(W, H, dev_pix, pix_stride)) {
-			fine16 = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
-			if (!fine16)
+		if (sq && !ctx->opt[DWTX_OPT_NO_FINE16] && dwtx_gray8_ok(W, H, dev_pix, pix_stride) && (fine16.levels = dwtx_levels16(W, H, sq, 5))) {
+			fine16.planes = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
+			if (!fine16.planes)
 				return DWTX_ERR_NOMEM;
 		}
 	}
@@ -167,13 +169,17 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 		int *lin = a + plane_ints * C * first;
 		int *pyr = b + plane_ints * C * first;
 		int *img = a + plane_ints * C * first;   // lin is dead once reconstructed
-		int16_t *f16 = (fused & DWTX_FUSED_FINE16) ? fine16 + plane_ints * C * first : nullptr;   // the decoder put the part's finest ring there
+		dwtx_p16 f16 = { nullptr, 0u };
+		if (fused & DWTX_FUSED_FINE16) {   // the decoder put the part's finest rings there
+			f16.planes = fine16.planes + plane_ints * C * first;
+			f16.levels = fine16.levels;
+		}
 		fused &= ~DWTX_FUSED_FINE16;
 		int r;
 		if ((r = dwtx_reconstruction_ex(ctx, pyr, lin, miss, lo, W, H, C, count, fused, f16)))    // decode.c:257 (the rest of it)
 			return r;
 		if (dwtx_gray8_ok(ow, oh, dev_pix + pix_stride * first, pix_stride))
-			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count, f16);   // decode.c:258-264
+			return dwtx_inv_pixels8(ctx, dev_pix + pix_stride * first, pix_stride, pyr, ow, oh, C, count, &f16);   // decode.c:258-264
 		if ((r = dwtx_transformation_inv(ctx, img, pyr, ow, oh, count * C)))                 // decode.c:258
 			return r;
 		if (count == 1 || (size_t)ow * oh * C == pix_stride)

@@ -112,7 +112,8 @@ enum {
 // shape allows it; image i of the inverse is written at pix + i*image_stride.
 bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride);
 int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n);   // C = 3: YCoCg-R fused too (image.h:52-65)
-int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n, const int16_t *fine16 = nullptr);   // C = 3: image.h:39-50 fused too
+struct dwtx_p16;
+int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n, const dwtx_p16 *p16 = nullptr);   // C = 3: image.h:39-50 fused too
 
 // The entropy stage's tiles (linearize.hip): the Hilbert curve of ring level l visits every aligned 32x32 square of
 // its lengths[l+1]-sided square contiguously ("curve block"), so the ring's coefficients, in the order of
@@ -144,12 +145,17 @@ struct dwtx_hist_sink {
 };
 int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *sink);   // pack.hip
 // lift.hip: the forward transform with the histograms of the levels it can take (returned in *hist_levels, bit l = ring level l)
-// fine16 (optional, everywhere below): the finest ring's coefficients are kept as 16-bit values in planes of their own
-// — [n*C][H][W] int16, the positions of the pyramid — instead of in the int32 pyramid, whose three outer quadrants are
-// then never touched.  An 8-bit source cannot leave 16 bits on that ring (|HL|, |LH|, |HH| <= 1020: cdf53.h:13-21 on
-// samples of magnitude <= 255), and it is three quarters of everything the entropy stage reads and writes.
+// p16 (optional, everywhere below): the detail coefficients of the ring levels in `levels` (a mask; the finest levels)
+// are kept as 16-bit values in planes of their own — [n*C][H][W] int16, the positions of the pyramid — instead of in the
+// int32 pyramid, whose positions for those rings are then never touched.  An 8-bit source cannot leave 16 bits on
+// its finest ring (|HL|, |LH|, |HH| <= 1020: cdf53.h:13-21 on samples of magnitude <= 255) — three quarters of
+// everything the entropy stage reads and writes; a decoder may keep every ring that way whose streams claim at most 15 bit planes.
+struct dwtx_p16 {
+	int16_t *planes;
+	unsigned levels;
+};
 int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels,
-	int16_t *fine16 = nullptr);
+	dwtx_p16 p16 = dwtx_p16{ nullptr, 0u });
 int dwtx_transformation_fwd_hist(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes, const dwtx_hist_sink *sink,
 	unsigned *hist_levels);
 int dwtx_get_tiles(dwtx_ctx *ctx, int W, int H, dwtx_tiles *out);
@@ -158,22 +164,24 @@ int dwtx_get_tiles(dwtx_ctx *ctx, int W, int H, dwtx_tiles *out);
 // squares need no linearised copy — the entropy stage reads (pack.hip) / writes (unpack.hip) them in the pyramid itself;
 // only the blocks the ring's edges cut (image border, LL quadrant) still go through `lin`.
 unsigned dwtx_square_levels(int W, int H);
-bool dwtx_fine16_ok(int W, int H, unsigned sq_levels);   // the finest ring is among the levels in the mask (then it may live in 16-bit planes)
+// the up to `max_levels` finest ring levels that may live in 16-bit planes: whole squares read / written in place (in
+// sq_levels) and transformed by the 16-byte-per-lane lifting kernels; 0 if the finest one does not qualify
+unsigned dwtx_levels16(int W, int H, unsigned sq_levels, int max_levels);
 int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels,
-	const int16_t *fine16 = nullptr);
+	dwtx_p16 p16 = dwtx_p16{ nullptr, 0u });
 int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing, int levels_out, int W, int H,
-	int C, int n, unsigned skip_levels, int16_t *fine16 = nullptr);
+	int C, int n, unsigned skip_levels, dwtx_p16 p16 = dwtx_p16{ nullptr, 0u });
 // hist_levels: ring levels whose tile histograms the forward transform has already written (dwtx_hist_begin)
 int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C, int n,
-	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info, const int16_t *fine16 = nullptr);
+	long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info, dwtx_p16 p16 = dwtx_p16{ nullptr, 0u });
 
 // unpack.hip: dwtx_decode_planes with a host callback per finished part of the batch (see there)
 // `pyr` (optional): pyramid planes [n*C][H][W]; for parts of the batch that decode at full resolution the tiles of
 // the full-square ring levels are written there (bias included) and `done` is told which levels (fused_levels).
-constexpr unsigned DWTX_FUSED_FINE16 = 1u << 31;   // in `fused_levels`: the part's finest ring was written to fine16, not to pyr
+constexpr unsigned DWTX_FUSED_FINE16 = 1u << 31;   // in `fused_levels`: the part's rings of p16.levels were written to the 16-bit planes, not to pyr
 int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8_t *streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
-	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user, int16_t *fine16 = nullptr);
+	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user, dwtx_p16 p16 = dwtx_p16{ nullptr, 0u });
 
 // The wave's lanes for which `pred` holds.  (HIP's __ballot() takes an int: the condition would be turned
 // into 0/1 in a register and compared again — two extra instructions per use in the ballot-heavy kernels.)

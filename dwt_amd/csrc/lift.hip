@@ -1595,7 +1595,7 @@ static int pick_rpw(int strips_x, int h2, int nplanes)
 // in8 != nullptr: the source is 8-bit pixels, gray (in8_channels 1: plane p = image p) or interleaved RGB
 // (in8_channels 3: plane p = channel p%3 of image p/3 after YCoCg-R); needs a finest level the wide kernel takes
 static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_t *in8, int in8_channels, int W, int H, int nplanes,
-	const dwtx_hist_sink *sink = nullptr, unsigned *hist_levels = nullptr, int16_t *fine16 = nullptr)
+	const dwtx_hist_sink *sink = nullptr, unsigned *hist_levels = nullptr, dwtx_p16 p16 = dwtx_p16{ nullptr, 0u })
 {
 	if (hist_levels)
 		*hist_levels = 0u;
@@ -1685,10 +1685,10 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 		a.det_ps = full_ps;
 		a.dpitch = W;
 		a.det16 = nullptr;
-		if (fine16 && t == 0) {
-			if (!bytes_in || !aligned_to(fine16, 4))   // (8-bit sources only: that is what bounds the ring's magnitudes)
+		if (p16.planes && ((p16.levels >> (T - 1 - t)) & 1u)) {
+			if (t != 0 || !bytes_in || !aligned_to(p16.planes, 4))   // (the finest ring of an 8-bit source: that is what bounds the magnitudes)
 				return DWTX_ERR_ARG;
-			a.det16 = fine16;
+			a.det16 = p16.planes;
 		}
 		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 &&
 			(bytes_in ? aligned_to(a.src8, 4) : aligned_to(a.src, 16)) &&
@@ -1760,11 +1760,11 @@ bool dwtx_gray8_ok(int W, int H, const void *pix, size_t image_stride)
 }
 
 int dwtx_fwd_pixels8_hist(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int H, int C, int n, const dwtx_hist_sink *sink, unsigned *hist_levels,
-	int16_t *fine16)
+	dwtx_p16 p16)
 {
 	if (!pix || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, (size_t)W * H * C))
 		return DWTX_ERR_ARG;
-	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C, sink, hist_levels, fine16);
+	return lift_fwd(ctx, out, nullptr, pix, C, W, H, n * C, sink, hist_levels, p16);
 }
 
 int dwtx_transformation_fwd_hist(dwtx_ctx *ctx, int32_t *out, const int32_t *in, int W, int H, int nplanes, const dwtx_hist_sink *sink,
@@ -1785,7 +1785,7 @@ int dwtx_fwd_pixels8(dwtx_ctx *ctx, int32_t *out, const uint8_t *pix, int W, int
 // out8 != nullptr: the finest level writes clamped 8-bit pixels (gray, or interleaved RGB after the
 // inverse colour transform when out8_channels == 3), image i at out8 + i*out8_ps
 static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, int out8_channels, const int32_t *in, int W, int H, int nplanes,
-	const int16_t *fine16 = nullptr)
+	const dwtx_p16 *p16 = nullptr)
 {
 	if (!ctx || (!out && !out8) || !in || W < 2 || H < 2 || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -1869,16 +1869,16 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 		a.det_ps = full_ps;
 		a.dpitch = W;
 		a.det16 = nullptr;
-		if (fine16 && t == 0) {
-			if (!bytes_out || !aligned_to(fine16, 4))
+		if (p16 && p16->planes && ((p16->levels >> (T - 1 - t)) & 1u)) {   // this level's detail bands are 16-bit values
+			if (!out8 || !aligned_to(p16->planes, 4))
 				return DWTX_ERR_ARG;
-			a.det16 = const_cast<short *>(fine16);
+			a.det16 = p16->planes;
 		}
 		const bool wide = a.w % 4 == 0 && a.llpitch % 4 == 0 && a.ll_ps % 4 == 0 &&
 			(bytes_out ? aligned_to(a.dst8, 4) : aligned_to(a.ll, 16)) &&
 			a.spitch % 2 == 0 && a.src_ps % 2 == 0 && aligned_to(a.src, 8) &&
 			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
-		if (bytes_out && !wide)
+		if ((bytes_out || a.det16) && !wide)
 			return DWTX_ERR_ARG;
 		if (wide) {
 			LevelArgsW A;
@@ -1898,6 +1898,8 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 				hipLaunchKernelGGL((k_inv_level_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_out)
 				hipLaunchKernelGGL((k_inv_level_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else if (a.det16)
+				hipLaunchKernelGGL((k_inv_level_w<int, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
 				hipLaunchKernelGGL((k_inv_level_w<int, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
@@ -1918,9 +1920,9 @@ extern "C" int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *out, const int32_
 	return lift_inv(ctx, out, nullptr, 0, 0, in, W, H, nplanes);
 }
 
-int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n, const int16_t *fine16)
+int dwtx_inv_pixels8(dwtx_ctx *ctx, uint8_t *pix, size_t image_stride, const int32_t *in, int W, int H, int C, int n, const dwtx_p16 *p16)
 {
 	if (!pix || W < 2 || H < 2 || (C != 1 && C != 3) || !dwtx_gray8_ok(W, H, pix, image_stride))
 		return DWTX_ERR_ARG;
-	return lift_inv(ctx, nullptr, pix, (long)image_stride, C, in, W, H, n * C, fine16);
+	return lift_inv(ctx, nullptr, pix, (long)image_stride, C, in, W, H, n * C, p16);
 }

@@ -139,7 +139,7 @@ template <bool INVERSE>
 __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__restrict__ blockbase,
 	int *__restrict__ lin, long lin_ps, int *__restrict__ pyr, long pyr_ps, int ppitch,
 	const int *__restrict__ missing, int C, int nplanes, unsigned skip_levels, const int *__restrict__ block_list,
-	short *__restrict__ fine16, int fine_level)
+	short *__restrict__ fine16, unsigned lv16)
 {
 	__shared__ int wcount[THREADS / 64];
 	const int b = block_list ? block_list[blockIdx.x] : (int)blockIdx.x;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void k_ring_copy(LinGeom g, const int *__r
 	}
 	// (the finest ring of an 8-bit source may live in 16-bit planes of its own — dwtx_internal.h; its whole squares never come
 	// this way, the blocks the ring's edges cut do)
-	const bool f16 = fine16 != nullptr && l == fine_level;   // uniform
+	const bool f16 = fine16 != nullptr && ((lv16 >> l) & 1u);   // uniform
 	for (int plane = first; plane < last; ++plane) {
 		int *lp = lin + plane * lin_ps + g.pixels[l] + blockbase[b];
 		int *pp = pyr + plane * pyr_ps;
@@ -549,12 +549,20 @@ unsigned dwtx_square_levels(int W, int H)
 	return mask;
 }
 
-bool dwtx_fine16_ok(int W, int H, unsigned sq_levels)
+unsigned dwtx_levels16(int W, int H, unsigned sq_levels, int max_levels)
 {
 	dwtx_geom g;
 	if (dwtx_geometry(&g, W, H) || g.levels < 1)
-		return false;
-	return ((sq_levels >> (g.levels - 1)) & 1u) != 0u;
+		return 0u;
+	unsigned mask = 0u;
+	for (int t = 0; t < max_levels && t < g.levels; ++t) {
+		const int l = g.levels - 1 - t;           // ring level of lifting step t
+		const int w = g.widths[l + 1], h = g.heights[l + 1];   // what that step transforms
+		if (!((sq_levels >> l) & 1u) || w % 4 != 0 || (w <= 64 && h <= 64))   // (lift.hip: wide kernel, not the LDS tail)
+			break;
+		mask |= 1u << l;
+	}
+	return mask;
 }
 
 extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes)
@@ -564,7 +572,7 @@ extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *py
 
 // skip_levels: ring levels that are NOT copied (their tiles are read from the pyramid by the entropy stage)
 int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels,
-	const int16_t *fine16)
+	dwtx_p16 p16)
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
@@ -574,7 +582,7 @@ int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W
 	if (rc)
 		return rc;
 	const LinGeom &g = p->g;
-	if (fine16 && !((skip_levels >> (g.levels - 1)) & 1u))   // (the finest ring's whole squares are the entropy stage's to read)
+	if (p16.planes && (p16.levels & ~skip_levels))   // (those rings' whole squares are the entropy stage's to read)
 		return DWTX_ERR_ARG;
 	const long ps = (long)W * H;
 	hipLaunchKernelGGL(k_root_copy<false>, dim3(dwtx_cdiv(g.pixels[0], 64), nplanes), dim3(64), 0, ctx->stream,
@@ -585,7 +593,7 @@ int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W
 	if (nb)
 		hipLaunchKernelGGL(k_ring_copy<false>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0, ctx->stream,
 			g, p->d_blockbase, lin, ps, const_cast<int *>(pyr), ps, W, (const int *)nullptr, 1, nplanes, skip_levels,
-			listed ? (const int *)p->d_copy_list : (const int *)nullptr, const_cast<short *>(fine16), g.levels - 1);
+			listed ? (const int *)p->d_copy_list : (const int *)nullptr, p16.planes, p16.planes ? p16.levels : 0u);
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;
 }
@@ -598,7 +606,7 @@ extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *l
 
 // skip_levels: ring levels the decoder's entropy stage has already written into the pyramid (with their bias)
 int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
-	int levels_out, int W, int H, int C, int n, unsigned skip_levels, int16_t *fine16)
+	int levels_out, int W, int H, int C, int n, unsigned skip_levels, dwtx_p16 p16)
 {
 	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || (C != 1 && C != 3) || n < 1 || n * C > 65535)
 		return DWTX_ERR_ARG;
@@ -610,9 +618,8 @@ int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, cons
 	LinGeom g = p->g;
 	if (levels_out < 0 || levels_out > g.levels)
 		return DWTX_ERR_ARG;
-	if (fine16 && (levels_out != g.levels || !((skip_levels >> (g.levels - 1)) & 1u)))   // whole pictures only
+	if (p16.planes && (levels_out != g.levels || (p16.levels & ~skip_levels)))   // whole pictures only
 		return DWTX_ERR_ARG;
-	const int fine_level = g.levels - 1;
 	const int ow = g.widths[levels_out], oh = g.heights[levels_out];
 	const long lin_ps = (long)W * H;
 	const long pyr_ps = (long)ow * oh;
@@ -626,7 +633,7 @@ int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, cons
 		if (nb)
 			hipLaunchKernelGGL(k_ring_copy<true>, dim3(nb, dwtx_cdiv(nplanes, PLANES_PER_GROUP)), dim3(THREADS), 0,
 				ctx->stream, g, p->d_blockbase, const_cast<int *>(lin), lin_ps, pyr, pyr_ps, ow, dev_missing, C, nplanes, skip_levels,
-				listed ? (const int *)p->d_copy_list : (const int *)nullptr, fine16, fine_level);
+				listed ? (const int *)p->d_copy_list : (const int *)nullptr, p16.planes, p16.planes ? p16.levels : 0u);
 	}
 	DWTX_LAUNCH_CHECK();
 	return DWTX_OK;

@@ -67,7 +67,8 @@ struct PackGeom {
 	int levels, C, W, H;
 	long total;
 	const int *pyr;        // wavelet pyramid of the same planes (pitch W), or null
-	const short *fine16;   // or null: the finest ring (level levels-1) is not in pyr but here, as 16-bit coefficients (same pitch and positions)
+	const short *fine16;   // or null: the rings of the levels in lv16 are not in pyr but here, as 16-bit coefficients (same pitch and positions)
+	unsigned lv16;
 	unsigned sq_levels;    // ring levels whose tiles are read from the pyramid's 32x32 squares instead of `lin` (hilbert_dev.h)
 	int side[DWTX_MAX_LEVELS + 1];          // outer side of ring level l (lengths[l+1])
 	int pixels[DWTX_MAX_LEVELS + 1];
@@ -199,7 +200,7 @@ __device__ __forceinline__ void load_tile16(const PackGeom &g, const int *__rest
 	int nv, unsigned *lds, int (&val)[16])
 {
 	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {   // uniform
-		if (g.fine16 && l == g.levels - 1)
+		if ((g.lv16 >> l) & 1u)
 			load_square16(g.fine16 + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
 		else
 			load_square16(g.pyr + (long)plane * g.total, g.W, g.side[l], g.tile_blk[tile], lane, lds, val);
@@ -282,7 +283,7 @@ __device__ __forceinline__ void hist_load(const PackGeom &g, const int *__restri
 		// every lane takes four consecutive coefficients of four rows
 		const SquareMap m = square_map(g.side[l], (unsigned)g.tile_blk[tile]);
 		const long at = (long)plane * g.total + (long)(m.my & ~31u) * g.W + (m.mx & ~31u);
-		if (g.fine16 && l == g.levels - 1) {   // 16-bit rows: eight coefficients of two rows
+		if ((g.lv16 >> l) & 1u) {   // 16-bit rows: eight coefficients of two rows
 			const short *sq = g.fine16 + at;
 #pragma unroll
 			for (int it = 0; it < 2; ++it) {
@@ -2397,6 +2398,7 @@ static int pack_geometry(dwtx_ctx *ctx, int W, int H, int C, int n, PackGeom &g,
 	}
 	g.pyr = nullptr;
 	g.fine16 = nullptr;
+	g.lv16 = 0u;
 	g.sq_levels = 0;
 	g.C = C;
 	g.W = W;
@@ -2448,7 +2450,7 @@ int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *s
 // pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
 // 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
 int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C,
-	int n, long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info, const int16_t *fine16)
+	int n, long capacity, uint8_t *out, size_t out_stride, dwtx_stream_info *dev_info, dwtx_p16 p16)
 {
 	if (!ctx || !lin || !out || !dev_info || (C != 1 && C != 3) || n < 1 || n > 65535 || (out_stride & 3) || out_stride < 8)
 		return DWTX_ERR_ARG;
@@ -2466,8 +2468,9 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	}
 	g.pyr = pyr;
 	g.sq_levels = sq_levels;
-	g.fine16 = fine16;
-	if (fine16 && (!((sq_levels >> (g.levels - 1)) & 1u) || ((uintptr_t)fine16 & 15)))   // (its whole squares only: the cut blocks come through lin)
+	g.fine16 = p16.planes;
+	g.lv16 = p16.planes ? p16.levels : 0u;
+	if (p16.planes && ((p16.levels & ~sq_levels) || ((uintptr_t)p16.planes & 15)))   // (whole squares only: the cut blocks come through lin)
 		return DWTX_ERR_ARG;
 	const int NT = tiles.NT;
 	// k_hist counts the tiles of the levels the forward transform has not done; when those are the coarse levels only (the

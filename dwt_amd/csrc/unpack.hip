@@ -69,7 +69,8 @@ struct UnpackGeom {
 	int tile_first[DWTX_MAX_LEVELS + 1];
 	int levels_max;                           // decode.c:163-171 PIXELS cap
 	int *pyr;                                 // pyramid planes (pitch W) that take the tiles of the levels in sq_levels, or null
-	short *fine16;                            // or null: the finest ring's squares go here as 16-bit coefficients instead (same positions and pitch)
+	short *fine16;                            // or null: the squares of the ring levels in lv16 go here as 16-bit coefficients instead (same positions and pitch)
+	unsigned lv16;
 	unsigned sq_levels;                       // ring levels written as 32x32 squares of the pyramid instead of into `lin` (hilbert_dev.h)
 	int side[DWTX_MAX_LEVELS + 1];            // outer side of ring level l (lengths[l+1])
 	// the tiles (dwtx_tiles): ring index of a tile's first coefficient, its coefficients, its block on the level's curve
@@ -2020,7 +2021,7 @@ __global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const 
 				v += v < 0 ? -bias : bias;
 			val[i] = v;
 		}
-		if (g.fine16 && l == g.levels - 1)
+		if ((g.lv16 >> l) & 1u)
 			store_square16(g.fine16 + (long)plane * g.lin_stride, g.W, g.side[l], g.tile_blk[tile], lane, ap_mem[threadIdx.x >> 6], val);
 		else
 			store_square16(g.pyr + (long)plane * g.lin_stride, g.W, g.side[l], g.tile_blk[tile], lane, ap_mem[threadIdx.x >> 6], val);
@@ -2083,7 +2084,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // there while the rest of the batch is still being decoded.
 int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8_t *streams, size_t stream_stride,
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max, dwtx_decode_info *host_info,
-	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user, int16_t *fine16)
+	int (*done)(void *user, int first, int count, unsigned fused_levels), void *user, dwtx_p16 p16)
 {
 	if (!ctx || !lin || !streams || !dev_lens || !host_info || (C != 1 && C != 3) || n < 1 || n > 65535 / 3 ||
 		(stream_stride & 7) || stream_stride < 64)
@@ -2105,6 +2106,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 	g.levels_max = levels_max < 0 || levels_max > g.levels ? g.levels : levels_max;
 	g.pyr = nullptr;
 	g.fine16 = nullptr;
+	g.lv16 = 0u;
 	g.sq_levels = 0;
 	{
 		dwtx_geom gg;
@@ -2444,8 +2446,9 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		ga.pyr = whole ? pyr + (size_t)i0 * C * g.lin_stride : nullptr;
 		// 16-bit planes for the finest ring if the caller keeps them and no stream of the part claims coefficients
 		// beyond 15 bits (an 8-bit source never does; a damaged stream may: then the part stays in the int32 pyramid)
-		const bool fine = whole && fine16 && !((uintptr_t)fine16 & 15) && ((sq_all >> (g.levels - 1)) & 1u) && pmax <= 15;
-		ga.fine16 = fine ? fine16 + (size_t)i0 * C * g.lin_stride : nullptr;
+		const bool fine = whole && p16.planes && p16.levels && !((uintptr_t)p16.planes & 15) && !(p16.levels & ~sq_all) && pmax <= 15;
+		ga.fine16 = fine ? p16.planes + (size_t)i0 * C * g.lin_stride : nullptr;
+		ga.lv16 = fine ? p16.levels : 0u;
 		part_mask[part_of(i0)] = ga.sq_levels | (fine ? DWTX_FUSED_FINE16 : 0u);
 		hipLaunchKernelGGL(k_apply_all, dim3(dwtx_cdiv(NT, 4), cnt * C), dim3(256), 0, st, ga, h,
 			streams + (size_t)i0 * stream_stride, (long)stream_stride, lin + (size_t)i0 * C * g.lin_stride);
