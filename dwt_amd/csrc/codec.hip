@@ -37,12 +37,13 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 		return rc;
 	// encode.c:160: levels that are full power-of-two squares stay in the pyramid (the coder reads their tiles there)
 	const unsigned sq = ctx->opt[DWTX_OPT_NO_SQUARE_TILES] ? 0u : dwtx_square_levels(W, H);
-	// The finest ring — three quarters of all coefficients — as 16-bit values in planes of its own when the transform
-	// starts from 8-bit pixels (no coefficient of that ring can leave 11 bits then) and the coder reads its squares in
-	// place: the transform writes, and the coder reads, half the bytes for it.
+	// The finest rings (up to five levels) as 16-bit values in planes of their own when the transform starts from 8-bit
+	// pixels — the finest ring, three quarters of all coefficients, cannot leave 11 bits then, the fifth level's not 15
+	// (lift.hip k_fwd_level_w) — and the coder reads their squares in place: the transform writes, and the coder reads,
+	// half the bytes for them.
 	dwtx_p16 fine16 = { nullptr, 0u };
 	const bool from_pixels = dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C);
-	if (from_pixels && sq && !ctx->opt[DWTX_OPT_NO_FINE16] && (fine16.levels = dwtx_levels16(W, H, sq, 1))) {
+	if (from_pixels && sq && !ctx->opt[DWTX_OPT_NO_FINE16] && (fine16.levels = dwtx_levels16(W, H, sq, 5))) {
 		fine16.planes = (int16_t *)dwtx_scratch(ctx, SLOT_CD_F16, sizeof(int16_t) * (size_t)W * H * C * n);
 		if (!fine16.planes)
 			return DWTX_ERR_NOMEM;

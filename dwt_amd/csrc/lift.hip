@@ -41,6 +41,8 @@ struct LevelArgs {
 	const uint8_t *src8;   // forward, finest level of a gray image: 8-bit pixels instead of src (pnm.h:69-74 widening fused)
 	uint8_t *dst8;         // inverse, finest level of a gray image: clamped 8-bit pixels instead of ll (pnm.h:108 fused)
 	short *det16;          // or null: this level's detail bands live here as 16-bit values (same positions, pitch and plane stride as det)
+	const short *src16;    // forward, or null: the input band as 16-bit values (pitch and plane stride of src)
+	short *ll16;           // forward, or null: the LL band goes out as 16-bit values (pitch and plane stride of ll)
 };
 
 // ---------------------------------------------------------------- forward ---
@@ -500,6 +502,65 @@ __device__ __forceinline__ FwdRawI fwd_load_i(const int *__restrict__ row, const
 	return r;
 }
 
+// the same row when the band is kept as 16-bit values (the levels of an 8-bit source whose range allows it)
+struct FwdRawS {
+	uint2 x;          // x[4q .. 4q+3]
+	unsigned e;       // lane 0: x[4q-2], x[4q-1]; the other lanes: its low half = x[4q+4]
+};
+
+__device__ __forceinline__ FwdRawS fwd_load_i(const short *__restrict__ row, const LaneAtI &at)
+{
+	FwdRawS r;
+	r.x = *reinterpret_cast<const uint2 *>(row + at.main);
+	r.e = *reinterpret_cast<const unsigned *>(row + at.edge);
+	return r;
+}
+
+__device__ __forceinline__ FwdRaw widen(const FwdRawI &r)
+{
+	FwdRaw o;
+	o.x = r.x;
+	o.xr = r.e.x;
+	o.left = r.e;
+	return o;
+}
+
+__device__ __forceinline__ FwdRaw widen(const FwdRawS &r)
+{
+	FwdRaw o;
+	o.x = make_int4((int)(short)(r.x.x & 0xffffu), (int)r.x.x >> 16, (int)(short)(r.x.y & 0xffffu), (int)r.x.y >> 16);
+	o.xr = (int)(short)(r.e & 0xffffu);
+	o.left = make_int2(o.xr, (int)r.e >> 16);
+	return o;
+}
+
+__device__ __forceinline__ FwdRaw hold(const FwdRawS &r)
+{
+	FwdRawS h;
+	h.x = make_uint2(hold(r.x.x), hold(r.x.y));
+	h.e = hold(r.e);
+	return widen(h);
+}
+
+__device__ __forceinline__ void st2(short *p, I2 v)
+{
+	*reinterpret_cast<unsigned *>(p) = ((unsigned)v.a & 0xffffu) | ((unsigned)v.b << 16);
+}
+
+// the band a forward level reads, as the kernel variant sees it
+template <bool P16>
+struct SrcBand {
+	typedef const int *ptr;
+	typedef FwdRawI raw;
+	static __device__ __forceinline__ ptr of(const LevelArgs &a, long plane) { return a.src + plane * a.src_ps; }
+};
+template <>
+struct SrcBand<true> {
+	typedef const short *ptr;
+	typedef FwdRawS raw;
+	static __device__ __forceinline__ ptr of(const LevelArgs &a, long plane) { return a.src16 + plane * a.src_ps; }
+};
+
 __device__ __forceinline__ FwdRaw hold(const FwdRawI &r)
 {
 	FwdRaw o;
@@ -515,7 +576,12 @@ __device__ __forceinline__ FwdRaw hold(const FwdRawI &r)
 // everything.  So the loop works in batches of S row pairs: wait once (where the rows are moved to the registers they
 // are used from), send the previous batch's results out, ask for the next batch's rows, then compute S row pairs
 // without touching memory — by the next wait both the stores and the loads are a whole batch of arithmetic old.
-template <bool HIST>
+// P16: the level's input band and its detail bands are 16-bit values (levels 2..5 of an 8-bit source in the codec: with
+// |x| <= 255 a sample of level k's input stays below 255 * 2.25^(k-1) and its details below four times that — the
+// low-pass of cdf53.h:9-34 has an l1 norm of 1.5 per direction, the high-pass of 2 — i.e. 26 142 on the fifth level;
+// that bound is loose: the composed five-level response has an l1 norm of 7.95, 2 028 for 8-bit samples, and
+// tests/test_codec_gpu.py builds the picture that gets there); the arithmetic is int32 either way.
+template <bool HIST, bool P16>
 __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 {
 	const LevelArgs &a = A.a;
@@ -530,25 +596,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
 	const bool valid = q < A.nquads;
-	const int *src = a.src + plane * a.src_ps;
+	const typename SrcBand<P16>::ptr src = SrcBand<P16>::of(a, plane);
 	int *ll = a.ll + plane * a.ll_ps;
+	short *ll16 = a.ll16 ? a.ll16 + plane * a.ll_ps : nullptr;   // (uniform)
 	int *det = a.det + plane * a.det_ps;
+	short *det16 = P16 ? a.det16 + plane * a.det_ps : nullptr;
 
 	constexpr int S = 2;
 	const int jfirst = j0 > 0 ? j0 - 1 : 0;
 	const LaneAtI at = lane_at_i(q, lane, A.nquads);
 	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
-	{
-		const FwdRawI r0 = fwd_load_i(src + (long)(2 * jfirst) * a.spitch, at);
-		FwdRaw u;
-		u.x = r0.x;
-		u.xr = r0.e.x;
-		u.left = r0.e;
-		fwd_lift_w(u, q, lane, A.nquads, l0, h0);
-	}
+	fwd_lift_w(widen(fwd_load_i(src + (long)(2 * jfirst) * a.spitch, at)), q, lane, A.nquads, l0, h0);
 	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
 	FwdRaw cur[2 * S];
-	FwdRawI nxt[2 * S];
+	typename SrcBand<P16>::raw nxt[2 * S];
 #pragma unroll
 	for (int k = 0; k < 2 * S; ++k)
 		nxt[k] = fwd_load_i(rowp(2 * jfirst + 1 + k), at);
@@ -558,11 +619,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 		for (int s = 0; s < S; ++s) {
 			const int j = jb + s;
 			if (j >= j0 && j < j1 && valid) {
-				st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
-				st2(det + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
-				if (2 * j + 1 < a.h) {
-					st2(det + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
-					st2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+				if (ll16)
+					st2(ll16 + (long)j * a.llpitch + 2 * q, osl[s]);
+				else
+					st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
+				if (P16) {
+					st2(det16 + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
+					if (2 * j + 1 < a.h) {
+						st2(det16 + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
+						st2(det16 + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+					}
+				} else {
+					st2(det + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
+					if (2 * j + 1 < a.h) {
+						st2(det + (long)(a.h2 + j) * a.dpitch + 2 * q, odl[s]);
+						st2(det + (long)(a.h2 + j) * a.dpitch + a.w2 + 2 * q, odh[s]);
+					}
 				}
 			}
 		}
@@ -823,6 +895,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
 	int ch;
 	const uint8_t *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
 	int *ll = a.ll + plane * a.ll_ps;
+	short *ll16 = a.ll16 ? a.ll16 + plane * a.ll_ps : nullptr;      // (uniform)
 	int *det = a.det + plane * a.det_ps;
 	short *det16 = a.det16 ? a.det16 + plane * a.det_ps : nullptr;   // (uniform)
 
@@ -853,7 +926,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
 			const int j = jb + s;
 			if (j >= j0 && j < j1 && valid) {
 				const bool odd_in = 2 * j + 1 < a.h;
-				st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
+				if (ll16)
+					st2(ll16 + (long)j * a.llpitch + 2 * q, osl[s]);
+				else
+					st2(ll + (long)j * a.llpitch + 2 * q, osl[s]);
 				if (det16) {
 					st2(det16 + (long)j * a.dpitch + a.w2 + 2 * q, osh[s]);
 					if (odd_in) {
@@ -1685,17 +1761,27 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 		a.det_ps = full_ps;
 		a.dpitch = W;
 		a.det16 = nullptr;
-		if (p16.planes && ((p16.levels >> (T - 1 - t)) & 1u)) {
-			if (t != 0 || !bytes_in || !aligned_to(p16.planes, 4))   // (the finest ring of an 8-bit source: that is what bounds the magnitudes)
+		a.src16 = nullptr;
+		a.ll16 = nullptr;
+		// 16-bit bands (dwtx_p16): the levels in the mask write their details there; between two such levels the LL
+		// band travels as 16-bit values too (in the scratch planes, which are sized for int32).  Only from 8-bit pixels:
+		// that is what bounds the magnitudes (see k_fwd_level_w).
+		auto in_mask = [&](int step) { return p16.planes && step < T && step < tail_from && ((p16.levels >> (T - 1 - step)) & 1u); };
+		if (in_mask(t)) {
+			if (!in8 || (t == 0) != bytes_in || t > 4 || (t > 0 && !in_mask(t - 1)) || !aligned_to(p16.planes, 16))
 				return DWTX_ERR_ARG;
 			a.det16 = p16.planes;
+			if (t > 0)
+				a.src16 = reinterpret_cast<const short *>(src);
+			if (in_mask(t + 1))
+				a.ll16 = reinterpret_cast<short *>(a.ll);
 		}
 		const bool wide = a.w % 4 == 0 && a.spitch % 4 == 0 && a.src_ps % 4 == 0 &&
 			(bytes_in ? aligned_to(a.src8, 4) : aligned_to(a.src, 16)) &&
 			a.llpitch % 2 == 0 && a.ll_ps % 2 == 0 && aligned_to(a.ll, 8) &&
 			a.dpitch % 2 == 0 && a.det_ps % 2 == 0 && aligned_to(a.det, 8);
-		if (bytes_in && !wide)
-			return DWTX_ERR_ARG;   // callers check dwtx_gray8_ok() first
+		if ((bytes_in || a.det16) && !wide)
+			return DWTX_ERR_ARG;   // callers check dwtx_gray8_ok() / dwtx_levels16() first
 		const int level = T - 1 - t;   // the ring level this step's detail bands are
 		// (the RGB kernel is bound by its own arithmetic — every plane's launch unpacks the pixels and does the colour
 		// transform — and pays for the histogram in full: 3.2 -> 4.7 ms per 256 frames of 1080p against the 1.4 ms k_hist takes)
@@ -1723,14 +1809,18 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 					hipLaunchKernelGGL((k_fwd_pixels_w<Rgb8, true>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else if (bytes_in)
 					hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				else if (a.src16)
+					hipLaunchKernelGGL((k_fwd_level_w<true, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 				else
-					hipLaunchKernelGGL(k_fwd_level_w<true>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+					hipLaunchKernelGGL((k_fwd_level_w<true, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			} else if (bytes_in && in8_channels == 3)
 				hipLaunchKernelGGL((k_fwd_pixels_w<Rgb8, false>), rgb_grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else if (bytes_in)
 				hipLaunchKernelGGL((k_fwd_pixels_w<uint8_t, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
+			else if (a.src16)
+				hipLaunchKernelGGL((k_fwd_level_w<false, true>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 			else
-				hipLaunchKernelGGL(k_fwd_level_w<false>, grid, dim3(64 * WAVES), 0, ctx->stream, A);
+				hipLaunchKernelGGL((k_fwd_level_w<false, false>), grid, dim3(64 * WAVES), 0, ctx->stream, A);
 		} else {
 			const int sx = dwtx_cdiv(a.w2, 64);
 			a.rpw = pick_rpw(sx, a.h2, nplanes);

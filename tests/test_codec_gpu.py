@@ -478,6 +478,53 @@ def test_the_finest_ring_in_16_bit_planes_changes_nothing(ctx, shape, opts):
             assert (ref is None and o is None) or (o.shape == ref.shape and (o == ref).all())
 
 
+def test_the_largest_coefficients_an_8_bit_source_can_make(ctx, opts):
+    """The codec keeps the detail rings of the five finest levels — and, in the encoder, the LL bands between them — as
+    16-bit values.  Pictures built to drive single coefficients as far as 8-bit samples can: the
+    signs of the five-level high-pass response (the 5/3 low-pass four times, then the high-pass) as red / blue of an
+    RGB picture, i.e. Co = +-255 in that pattern, at the sub-pixel shifts that line it up with a level-5 HH
+    coefficient; and black / white noise at block sizes 1 .. 32.  Same bytes as the oracle (which computes in int),
+    and the same with the 16-bit planes switched off."""
+    g, h = np.array([-1, 2, 6, 2, -1]) / 8.0, np.array([-0.5, 1, -0.5])
+
+    def up(f, m):
+        o = np.zeros((len(f) - 1) * m + 1)
+        o[::m] = f
+        return o
+
+    low = np.array([1.0])
+    for k in range(4):
+        low = np.convolve(low, up(g, 2 ** k))
+    high5 = np.convolve(low, up(h, 16))
+    N = 2048
+    pics = []
+    for shift in (16, 0):
+        s1 = np.zeros(N)
+        st = N // 2 - len(high5) // 2 + shift
+        s1[st:st + len(high5)] = np.sign(high5)
+        pat = np.outer(s1, s1)
+        img = np.zeros((N, N, 3), dtype=np.uint8)
+        img[..., 0] = np.where(pat > 0, 255, 0)
+        img[..., 2] = np.where(pat < 0, 255, 0)
+        img[..., 1] = 128
+        pics.append(img)
+    coef, _, _ = orc.stage_dump(pics[0])
+    assert np.abs(coef).max() >= 2000    # (255 x the l1 norm of that response, 7.95: what this picture is for)
+    rng = np.random.default_rng(3)
+    blocks = np.zeros((N, N, 3), dtype=np.uint8)
+    for c, b in enumerate((1, 4, 32)):
+        blocks[..., c] = np.kron(rng.integers(0, 2, (N // b, N // b)), np.ones((b, b))).astype(np.uint8) * 255
+    pics.append(blocks)
+    pix = np.stack(pics)
+    want = [orc.encode(p)[0] for p in pix]
+    streams, _ = ctx.encode(pix)
+    assert streams == want
+    assert all((o == p).all() for o, p in zip(ctx.decode(streams), pix))
+    opts.set("no_fine16", 1)
+    assert ctx.encode(pix)[0] == want
+    assert all((o == p).all() for o, p in zip(ctx.decode(streams), pix))
+
+
 @pytest.mark.parametrize("case", [(64, 64, 1, 15), (64, 64, 1, 16), (128, 96, 3, 15), (128, 96, 3, 16), (192, 128, 1, 12)])
 def test_streams_with_15_or_16_bit_planes_on_the_finest_ring_decode_like_the_oracle(ctx, case):
     """No 8-bit source produces them, but a .dwt may hold them (encode.c:112-131 takes any int): streams coded by the
