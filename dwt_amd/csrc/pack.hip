@@ -1759,11 +1759,15 @@ struct WalkLds {
 	unsigned tok[64 * WROW];
 };
 
-__global__ __launch_bounds__(256) void k_gorder(Work w)
+// (two waves per workgroup: a wave's window is 8.7 KB of LDS, and 160 KB take nine workgroups of two — 18 waves per CU —
+// but only four of four)
+constexpr int GO_WAVES = 2;
+
+__global__ __launch_bounds__(64 * GO_WAVES) void k_gorder(Work w)
 {
-	__shared__ WalkLds lds[4];
+	__shared__ WalkLds lds[GO_WAVES];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const long wave = (long)blockIdx.x * 4 + wv;
+	const long wave = (long)blockIdx.x * GO_WAVES + wv;
 	const int img = blockIdx.y;
 	const ImgInfo &I = w.info[img];
 	const long T = I.T;
@@ -2000,7 +2004,7 @@ struct EmitLds {
 	unsigned win[EWIN];
 };
 
-__global__ __launch_bounds__(256) void k_emit(Work w, unsigned *out, long out_words)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(Work w, unsigned *out, long out_words)
 {
 	__shared__ EmitLds lds[4];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2593,7 +2597,7 @@ int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr,
 	hipLaunchKernelGGL(k_carry_local, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
 	hipLaunchKernelGGL(k_carry_blocks, dim3(n), dim3(CARRY_BLOCK), 0, s, w);
 	hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)w.NCB, n), dim3(CARRY_THREADS), 0, s, w);
-	hipLaunchKernelGGL(k_gorder, dim3((int)((w.NCS + 3) / 4), n), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_gorder, dim3((int)((w.NCS + GO_WAVES - 1) / GO_WAVES), n), dim3(64 * GO_WAVES), 0, s, w);
 	// exact pass: only images the fast pass flagged (their kernels return at once otherwise)
 	hipLaunchKernelGGL(k_lut, dim3(512, n), dim3(256), 0, s, w);
 	hipLaunchKernelGGL(k_chain_groups, dim3(64, n), dim3(256), 0, s, w);

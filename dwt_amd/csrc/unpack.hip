@@ -573,7 +573,7 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 // hands its successor to the work list (round 2).  The chunk's words are loaded once and no table travels through
 // memory between the two parses (rounds 1-2 used to be k_spec + k_link_all: 1.93 -> 1.77 ms per 64 frames).
 // A workgroup's first thread only speculates: its chunk is linked by the workgroup before (strides of 255 chunks).
-__global__ __launch_bounds__(256) void k_link_first(DWork w, const unsigned char *streams, long stream_stride)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64))) void k_link_first(DWork w, const unsigned char *streams, long stream_stride)
 {
 	__shared__ unsigned short sx[256];
 	const int vs = vstream(w, blockIdx.y), img = vs / FAM;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_link_first(DWork w, const unsigned char
 // later rounds: the chunks queued by the previous one.  Several percent after round 1, then slowly fewer: inside
 // the raw refinement blocks (most of a stream's bits) every parse is arbitrary and the paths there keep moving;
 // those records are never used, so the rounds are simply cut off (LINK_ROUNDS)
-__global__ __launch_bounds__(256) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64))) void k_link_work(DWork w, const unsigned char *streams, long stream_stride, int cur, int round)
 {
 	const int vs = vstream(w, blockIdx.y), shard = blockIdx.x % LINK_SHARDS, part = blockIdx.x / LINK_SHARDS,
 		parts = gridDim.x / LINK_SHARDS;
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void k_scan_add(DWork w)
 }
 
 // the tokens of every chunk (piece) the walker did not set itself -> symbits
-__global__ __launch_bounds__(256) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_hopbits(DWork w, const unsigned char *streams, long stream_stride)
 {
 	constexpr int HB_WORDS = 16;   // 256 symbols
 	constexpr int HB_WIN = 2048;   // the workgroup's window: 32768 symbols
@@ -1849,7 +1849,7 @@ __device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
 	return v;
 }
 
-__global__ __launch_bounds__(256) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
 {
 	// the deposit tables in LDS (4352 bytes, 17 per thread), before any wave leaves
 	__shared__ __attribute__((aligned(16))) unsigned char dep[sizeof(DepositTables)];
