@@ -525,7 +525,8 @@ def test_the_largest_coefficients_an_8_bit_source_can_make(ctx, opts):
     assert all((o == p).all() for o, p in zip(ctx.decode(streams), pix))
 
 
-@pytest.mark.parametrize("case", [(64, 64, 1, 15), (64, 64, 1, 16), (128, 96, 3, 15), (128, 96, 3, 16), (192, 128, 1, 12)])
+@pytest.mark.parametrize("case", [(64, 64, 1, 15), (64, 64, 1, 16), (128, 96, 3, 15), (128, 96, 3, 16), (192, 128, 1, 12), (1024, 512, 1, 15),
+                                  (512, 1024, 3, 15), (1024, 512, 1, 16)])
 def test_streams_with_15_or_16_bit_planes_on_the_finest_ring_decode_like_the_oracle(ctx, case):
     """No 8-bit source produces them, but a .dwt may hold them (encode.c:112-131 takes any int): streams coded by the
     oracle from arbitrary coefficient planes with magnitudes up to 2^bits - 1 on every ring.  15 bits still fit the
