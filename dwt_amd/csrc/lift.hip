@@ -1039,13 +1039,57 @@ __device__ __forceinline__ int2 ld2(const int *p) { return *reinterpret_cast<con
 struct InvAt {
 	int col;          // 2 * clamped quad
 	int jmax, jdmax;  // last row pair of the LL / HL bands, last of the LH / HH bands (an odd height has one row less there)
+	int colr, coll;   // the column after the lane's pair and the one before it (clamped to the band)
 };
 
 __device__ __forceinline__ InvAt inv_at(const LevelArgs &a, int qd, int nquads)
 {
-	InvAt o = { 2 * min(max(qd, 0), nquads - 1), a.h2 - 1, a.h / 2 - 1 };
+	const int col = 2 * min(max(qd, 0), nquads - 1);
+	InvAt o = { col, a.h2 - 1, a.h / 2 - 1, min(col + 2, 2 * nquads - 1), max(col - 1, 0) };
 	return o;
 }
+
+// The columns next to a lane's pair, as loaded: the inverse undoes the columns first, so the row step of a wave's
+// first and last lane needs its neighbours' samples AFTER their column step — every lane carries the column to the
+// right of its pair (both bands) and the high band's column to its left through the column step as well; only lanes
+// 0 and 63 use them (the others get the same values from their neighbours' registers), and what all 64 lanes load
+// for them are lines their neighbours load anyway.  (Before: waves that overlapped by eight lanes of 64, i.e. 14 %
+// more rows loaded than written.)
+struct InvHalo {
+	int sl_r, sh_r, dl_r, dh_r;   // LL | HL | LH | HH at column 2q+2
+	int sh_l, dh_l;               // HL | HH at column 2q-1
+};
+
+__device__ __forceinline__ InvHalo inv_load_halo(const LevelArgs &a, const int *llp, const int *det, int j, const InvAt &at)
+{
+	InvHalo r;
+	const int ja = min(j, at.jmax), jd = min(j, at.jdmax);
+	r.sl_r = llp[(long)ja * a.spitch + at.colr];
+	r.sh_r = det[(long)ja * a.dpitch + a.w2 + at.colr];
+	r.dl_r = det[(long)(a.h2 + jd) * a.dpitch + at.colr];
+	r.dh_r = det[(long)(a.h2 + jd) * a.dpitch + a.w2 + at.colr];
+	r.sh_l = det[(long)ja * a.dpitch + a.w2 + at.coll];
+	r.dh_l = det[(long)(a.h2 + jd) * a.dpitch + a.w2 + at.coll];
+	return r;
+}
+
+__device__ __forceinline__ InvHalo inv_load_halo(const LevelArgs &a, const int *llp, const short *det16, int j, const InvAt &at)
+{
+	InvHalo r;   // (16-bit bands: the load itself widens)
+	const int ja = min(j, at.jmax), jd = min(j, at.jdmax);
+	r.sl_r = llp[(long)ja * a.spitch + at.colr];
+	r.sh_r = det16[(long)ja * a.dpitch + a.w2 + at.colr];
+	r.dl_r = det16[(long)(a.h2 + jd) * a.dpitch + at.colr];
+	r.dh_r = det16[(long)(a.h2 + jd) * a.dpitch + a.w2 + at.colr];
+	r.sh_l = det16[(long)ja * a.dpitch + a.w2 + at.coll];
+	r.dh_l = det16[(long)(a.h2 + jd) * a.dpitch + a.w2 + at.coll];
+	return r;
+}
+
+// the halo columns as one more pair per band: .a = the column to the right, .b = the column to the left (high band only)
+struct HaloPairs {
+	I2 sl, sh, dl, dh;
+};
 
 __device__ __forceinline__ InvRawT<false> inv_load_w(const LevelArgs &a, const int *llp, const int *det, int j, const InvAt &at)
 {
@@ -1085,6 +1129,26 @@ __device__ __forceinline__ I2 to_i2(int2 v)
 {
 	I2 r = { v.x, v.y };
 	return r;
+}
+__device__ __forceinline__ I2 to_i2(I2 v) { return v; }
+
+__device__ __forceinline__ HaloPairs hold(const InvHalo &r)
+{
+	HaloPairs o;
+	o.sl.a = hold(r.sl_r);
+	o.sl.b = 0;
+	o.sh.a = hold(r.sh_r);
+	o.sh.b = hold(r.sh_l);
+	o.dl.a = hold(r.dl_r);
+	o.dl.b = 0;
+	o.dh.a = hold(r.dh_r);
+	o.dh.b = hold(r.dh_l);
+	return o;
+}
+__device__ __forceinline__ HaloPairs as_pairs(const InvHalo &r)
+{
+	HaloPairs o = { { r.sl_r, 0 }, { r.sh_r, r.sh_l }, { r.dl_r, 0 }, { r.dh_r, r.dh_l } };
+	return o;
 }
 
 __device__ __forceinline__ I2 to_i2(unsigned u)   // two 16-bit values
@@ -1185,9 +1249,14 @@ __device__ __forceinline__ InvCols inv_first(const LevelArgs &a, int j0, const R
 	return c;
 }
 
-// one row pair: its two output rows (the odd one only if it exists) from the state and the next pair's samples `n`
+// one row pair, the column step: the (low, high) samples of its even and its odd row from the state and the next
+// pair's samples `n`
+struct RowLH {
+	I2 lo, hi;
+};
+
 template <class Raw>
-__device__ __forceinline__ void inv_pair(const LevelArgs &a, int jj, int qd, int nquads, InvCols &c, const Raw &n, Quad4 &even, Quad4 &odd)
+__device__ __forceinline__ void inv_cols(const LevelArgs &a, int jj, InvCols &c, const Raw &n, RowLH &even, RowLH &odd)
 {
 	const int r1 = 2 * jj + 1;
 	I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = c.el, neh = c.eh;   // mirror x[h] := x[h-2]
@@ -1199,14 +1268,49 @@ __device__ __forceinline__ void inv_pair(const LevelArgs &a, int jj, int qd, int
 		nel = inv_even(a, jj + 1, to_i2(n.sl), c.dl, ndl);
 		neh = inv_even(a, jj + 1, to_i2(n.sh), c.dh, ndh);
 	}
-	even = inv_row_vals(qd, nquads, c.el, c.eh);
-	const I2 ol = { c.dl.a + tdiv2(c.el.a + nel.a), c.dl.b + tdiv2(c.el.b + nel.b) };   // cdf53.h:49-56
-	const I2 oh = { c.dh.a + tdiv2(c.eh.a + neh.a), c.dh.b + tdiv2(c.eh.b + neh.b) };
-	odd = inv_row_vals(qd, nquads, ol, oh);
+	even.lo = c.el;
+	even.hi = c.eh;
+	odd.lo.a = c.dl.a + tdiv2(c.el.a + nel.a);   // cdf53.h:49-56
+	odd.lo.b = c.dl.b + tdiv2(c.el.b + nel.b);
+	odd.hi.a = c.dh.a + tdiv2(c.eh.a + neh.a);
+	odd.hi.b = c.dh.b + tdiv2(c.eh.b + neh.b);
 	c.dl = ndl;
 	c.dh = ndh;
 	c.el = nel;
 	c.eh = neh;
+}
+
+// (waves that overlap by a lane on each side: the RGB kernel)
+template <class Raw>
+__device__ __forceinline__ void inv_pair(const LevelArgs &a, int jj, int qd, int nquads, InvCols &c, const Raw &n, Quad4 &even, Quad4 &odd)
+{
+	RowLH e, o;
+	inv_cols(a, jj, c, n, e, o);
+	even = inv_row_vals(qd, nquads, e.lo, e.hi);
+	odd = inv_row_vals(qd, nquads, o.lo, o.hi);
+}
+
+// the row step with the halo columns' samples x (x.lo.a, x.hi.a: the column to the right; x.hi.b: the one to the left)
+__device__ __forceinline__ Quad4 inv_row_vals_h(int qd, int nquads, int lane, const RowLH &r, const RowLH &x)
+{
+	int hl = __shfl_up(r.hi.b, 1);
+	if (lane == 0)
+		hl = x.hi.b;
+	if (qd <= 0)
+		hl = r.hi.a;
+	const int e0 = r.lo.a - tdiv4(hl + r.hi.a);
+	const int e1 = r.lo.b - tdiv4(r.hi.a + r.hi.b);
+	int er = __shfl_down(e0, 1);
+	if (lane == 63)
+		er = x.lo.a - tdiv4(r.hi.b + x.hi.a);
+	if (qd + 1 >= nquads)
+		er = e1;
+	Quad4 q;
+	q.v[0] = e0;
+	q.v[1] = r.hi.a + tdiv2(e0 + e1);
+	q.v[2] = e1;
+	q.v[3] = r.hi.b + tdiv2(e1 + er);
+	return q;
 }
 
 // Inverse level: int32 planes, or — the finest level of a gray image — clamped 8-bit pixels out (and, F16, the detail
@@ -1218,14 +1322,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	int bx, by;
 	xcd_strip(bx, by);
-	const int qd = bx * INV_QUADS - 1 + lane;
+	const int qd = bx * 64 + lane;   // all 64 lanes write: the halo columns ride along (InvHalo)
 	const int j0 = (by * WAVES + wv) * a.rpw;
 	if (j0 >= a.h2)
 		return;
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = blockIdx.z;
-	const bool valid = qd >= 0 && qd < A.nquads;
-	const bool writes = valid && lane >= 1 && lane <= INV_QUADS;
+	const bool writes = qd < A.nquads;
 	const int *llp = a.src + plane * a.src_ps;
 	const typename DetPtr<F16>::type det = DetPtr<F16>::of(a, plane);
 	typedef InvRawT<F16> InvRaw;
@@ -1234,11 +1337,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	const InvAt at = inv_at(a, qd, A.nquads);
 
 	constexpr int S = 2;
-	InvCols c = inv_first(a, j0, inv_load_w(a, llp, det, j0 > 0 ? j0 - 1 : 0, at), inv_load_w(a, llp, det, j0, at));
+	const int jb4 = j0 > 0 ? j0 - 1 : 0;
+	InvCols c = inv_first(a, j0, inv_load_w(a, llp, det, jb4, at), inv_load_w(a, llp, det, j0, at));
+	InvCols cx = inv_first(a, j0, as_pairs(inv_load_halo(a, llp, det, jb4, at)), as_pairs(inv_load_halo(a, llp, det, j0, at)));
 	InvRaw nxt[S], cur[S];
+	InvHalo nxtx[S];
+	HaloPairs curx[S];
 #pragma unroll
-	for (int s = 0; s < S; ++s)
+	for (int s = 0; s < S; ++s) {
 		nxt[s] = inv_load_w(a, llp, det, j0 + 1 + s, at);
+		nxtx[s] = inv_load_halo(a, llp, det, j0 + 1 + s, at);
+	}
 	typename Out::type orow[2 * S];   // a batch's rows wait here for the next iteration's stores
 	auto store_batch = [&](int jb) {
 #pragma unroll
@@ -1253,24 +1362,29 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	};
 	for (int jb = j0; jb < j1; jb += S) {
 #pragma unroll
-		for (int s = 0; s < S; ++s)
+		for (int s = 0; s < S; ++s) {
 			cur[s] = hold(nxt[s]);   // the one wait of the iteration
+			curx[s] = hold(nxtx[s]);
+		}
 		if (jb > j0)
 			store_batch(jb - S);
 		if (jb + S < j1) {
 #pragma unroll
-			for (int s = 0; s < S; ++s)
+			for (int s = 0; s < S; ++s) {
 				nxt[s] = inv_load_w(a, llp, det, jb + S + 1 + s, at);
+				nxtx[s] = inv_load_halo(a, llp, det, jb + S + 1 + s, at);
+			}
 		}
 #pragma unroll
 		for (int s = 0; s < S; ++s) {
 			const int jj = jb + s;
 			if (jj >= j1)
 				break;
-			Quad4 even, odd;
-			inv_pair(a, jj, qd, A.nquads, c, cur[s], even, odd);
-			orow[2 * s] = Out::of(even);
-			orow[2 * s + 1] = Out::of(odd);
+			RowLH e, o, ex, ox;
+			inv_cols(a, jj, c, cur[s], e, o);
+			inv_cols(a, jj, cx, curx[s], ex, ox);
+			orow[2 * s] = Out::of(inv_row_vals_h(qd, A.nquads, lane, e, ex));
+			orow[2 * s + 1] = Out::of(inv_row_vals_h(qd, A.nquads, lane, o, ox));
 		}
 	}
 	store_batch(j0 + (j1 - 1 - j0) / S * S);
@@ -1973,8 +2087,9 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 		if (wide) {
 			LevelArgsW A;
 			A.nquads = a.w / 4;
-			a.rpw = pick_rpw(dwtx_cdiv(A.nquads, INV_QUADS), a.h2, nplanes);
-			const int sx = dwtx_cdiv(A.nquads, INV_QUADS);
+			const int per_wave = bytes_out && out8_channels == 3 ? INV_QUADS : 64;   // (the RGB kernel's waves overlap by a lane on each side)
+			a.rpw = pick_rpw(dwtx_cdiv(A.nquads, per_wave), a.h2, nplanes);
+			const int sx = dwtx_cdiv(A.nquads, per_wave);
 			A.wx_log2 = 0;
 			A.a = a;
 			dim3 grid(sx, dwtx_cdiv(a.h2, WAVES * a.rpw), nplanes);
