@@ -75,7 +75,10 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 		return DWTX_ERR_ARG;
 	DWTX_ENTER(ctx);
 	DWTX_CHECK_DIMS(W, H);
-	const int K = ctx->opt[DWTX_OPT_ONE_STREAM] || n < 2 * DWTX_ENC_PARTS ? 1 : DWTX_ENC_PARTS;
+	// (parts pay from about 32 images each: measured at the end of round 3, when the transform no longer waits on memory
+	// the way it did — 1024 frames of 1080p RGB 43.2 -> 41.9 ms, 256 frames 11.0 -> 10.9, but 64 frames of 4096x4096 gray
+	// 6.57 -> 6.72 and 16 frames 1.98 -> 2.17 the wrong way)
+	const int K = ctx->opt[DWTX_OPT_ONE_STREAM] || n < 32 * DWTX_ENC_PARTS ? 1 : DWTX_ENC_PARTS;
 	if (K == 1)
 		return encode_part(ctx, dev_pix, W, H, C, n, capacity, dev_out, out_stride, dev_info, nullptr);
 	dwtx_ctx *part[DWTX_ENC_PARTS];

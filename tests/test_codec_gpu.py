@@ -554,6 +554,29 @@ def test_streams_with_15_or_16_bit_planes_on_the_finest_ring_decode_like_the_ora
             assert (r is None and o is None) or (o is not None and o.shape == r.shape and (o == r).all()), len(batch)
 
 
+def test_a_batch_large_enough_for_the_encoder_to_run_it_in_parts(ctx, opts):
+    """dwtx_encode_device cuts batches of 128 images and more into four staggered parts on the context's streams
+    (codec.hip); smaller ones run as one.  130 small images (uneven parts): the bytes of every stream equal the
+    oracle's, the pictures come back, and the one-stream run gives the same bytes."""
+    import torch
+
+    n, H, W, Cn = 130, 80, 96, 3
+    pix = ctx.synth_pixels(n, H, W, Cn, seed0=7, kind=0)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    host = pix.cpu().numpy()
+    got = [streams[i, : int(lens[i])].cpu().numpy().tobytes() for i in range(n)]
+    for i in (0, 1, 31, 32, 33, 64, 65, 97, 98, 129):
+        assert got[i] == orc.encode(host[i])[0], i
+    out, _ = ctx.decode_device(streams, lens, W, H, Cn)
+    assert torch.equal(out.view(n, H, W, Cn), pix)
+    opts.set("one_stream", 1)
+    streams1, info1 = ctx.encode_device(pix)
+    lens1 = ctx.stream_lengths(info1)
+    assert torch.equal(lens1, lens)
+    assert all(streams1[i, : int(lens[i])].cpu().numpy().tobytes() == got[i] for i in range(n))
+
+
 @pytest.mark.parametrize("parts", ["2", "3", "4"])
 def test_decode_batches_in_two_three_or_four_parts(ctx, parts, opts):
     """A decode batch runs as parts on streams of their own (unpack.hip dwtx_decode_planes_ex; four from 24 images on):
