@@ -6,6 +6,8 @@ W, H, C, n = (int(v) for v in sys.argv[1:5])
 ctx = dwt_amd.Context(0)
 if os.environ.get("DWTX_ONE_STREAM"):
     ctx.set_option("one_stream", 1)
+if os.environ.get("DWTX_DECODE_PARTS"):
+    ctx.set_option("decode_parts", int(os.environ["DWTX_DECODE_PARTS"]))
 pix = ctx.synth_pixels(n, H, W, C, 0, 0)
 streams, info = ctx.encode_device(pix)
 lens = ctx.stream_lengths(info)
