@@ -1659,10 +1659,36 @@ __device__ __forceinline__ int walk_order(const unsigned *my, const unsigned *bi
 	return o;
 }
 
-// two chains at once (start orders 0 and 31): see k_gorder.  Once the chains of every lane have met
-// (typically after 10-20 tokens) the rest of the group is walked with one chain.
-__device__ __forceinline__ void walk_order2(const unsigned *my, const unsigned *big, long tb, int &lo, int &hi)
+// bits of one token pair x (run values v) coded from order o — o moves on — and of the refinement blocks that follow
+// its break slots (t = index of the pair's first token)
+__device__ __forceinline__ void pair_bits(unsigned x, const unsigned (&v)[2], long t, int &o, bool count_raw,
+	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
 {
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const unsigned tk = e ? x >> 16 : x & 0xffffu;
+		const int top = vli_top(o, v[e]);
+		const unsigned nb = (unsigned)(2 * top - o + 1) + ((tk & T_NOSIGN) ? 0u : 1u);
+		tokbits += (tk & T_VOID) ? 0u : nb;
+		o = (tk & T_VOID) ? o : vli_next(top);
+	}
+	if (pair_has_break(x) && count_raw) {
+#pragma unroll
+		for (int e = 0; e < 2; ++e)
+			if ((e ? x >> 16 : x) & T_BREAK)
+				rawbits += srefs[find_break_seg(btok, K, (unsigned)(t + e))];
+	}
+}
+
+// two chains at once (start orders 0 and 31): see k_gorder.  Once the chains of every lane have met
+// (typically after 10-20 tokens) the rest of the group is walked with one chain — whose orders are the group's
+// whatever it is entered with, so the bits of those tokens are counted on the way (tokbits, rawbits).  Returns the
+// token quad the single chain started at (16: the chains did not meet): walk_bits only has to do the quads before it.
+__device__ __forceinline__ int walk_order2(const unsigned *my, const unsigned *big, long tb, int &lo, int &hi, bool count_raw,
+	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
+{
+	tokbits = 0;
+	rawbits = 0;
 	int q = 0;
 	bool met = false;   // uniform
 	for (; q < 16; q += 2) {
@@ -1689,33 +1715,8 @@ __device__ __forceinline__ void walk_order2(const unsigned *my, const unsigned *
 			}
 		}
 	}
+	const int qmet = q;
 	for (; q < 16; ++q) {
-		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
-		const unsigned xs[2] = { x2.x, x2.y };
-#pragma unroll
-		for (int h = 0; h < 2; ++h) {
-			const unsigned x = xs[h];
-			unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
-			if (pair_has_esc(x)) {
-				v0 = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
-				v1 = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
-			}
-			lo = vli_step(lo, v0, x & T_VOID);
-			lo = vli_step(lo, v1, (x >> 16) & T_VOID);
-		}
-	}
-	if (met)
-		hi = lo;   // hi was left behind in the single-chain part
-}
-
-// bits of one group's tokens coded from order o, and of the refinement blocks that follow its break slots
-__device__ __forceinline__ void walk_bits(const unsigned *my, const unsigned *big, long tb, int o, bool count_raw,
-	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
-{
-	tokbits = 0;
-	rawbits = 0;
-#pragma unroll 4
-	for (int q = 0; q < 16; ++q) {
 		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
 		const unsigned xs[2] = { x2.x, x2.y };
 #pragma unroll
@@ -1726,20 +1727,31 @@ __device__ __forceinline__ void walk_bits(const unsigned *my, const unsigned *bi
 				v[0] = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
 				v[1] = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
 			}
+			pair_bits(x, v, tb + 4 * q + 2 * h, lo, count_raw, btok, srefs, K, tokbits, rawbits);
+		}
+	}
+	if (met)
+		hi = lo;   // hi was left behind in the single-chain part
+	return qmet;
+}
+
+// bits of a group's first 4 * qend tokens coded from order o, added to tokbits / rawbits
+__device__ __forceinline__ void walk_bits(const unsigned *my, const unsigned *big, long tb, int o, int qend, bool count_raw,
+	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
+{
+#pragma unroll 2
+	for (int q = 0; q < qend; ++q) {
+		const uint2 x2 = *reinterpret_cast<const uint2 *>(my + 2 * q);
+		const unsigned xs[2] = { x2.x, x2.y };
 #pragma unroll
-			for (int e = 0; e < 2; ++e) {
-				const unsigned tk = e ? x >> 16 : x & 0xffffu;
-				const int top = vli_top(o, v[e]);
-				const unsigned nb = (unsigned)(2 * top - o + 1) + ((tk & T_NOSIGN) ? 0u : 1u);
-				tokbits += (tk & T_VOID) ? 0u : nb;
-				o = (tk & T_VOID) ? o : vli_next(top);
+		for (int h = 0; h < 2; ++h) {
+			const unsigned x = xs[h];
+			unsigned v[2] = { x & T_RUN, (x >> 16) & T_RUN };
+			if (pair_has_esc(x)) {
+				v[0] = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
+				v[1] = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
 			}
-			if (pair_has_break(x) && count_raw) {
-#pragma unroll
-				for (int e = 0; e < 2; ++e)
-					if ((e ? x >> 16 : x) & T_BREAK)
-						rawbits += srefs[find_break_seg(btok, K, (unsigned)(tb + 4 * q + 2 * h + e))];
-			}
+			pair_bits(x, v, tb + 4 * q + 2 * h, o, count_raw, btok, srefs, K, tokbits, rawbits);
 		}
 	}
 }
@@ -1784,8 +1796,12 @@ __global__ __launch_bounds__(64 * GO_WAVES) void k_gorder(Work w)
 	const unsigned *my = rows + lane * WROW;
 	const long tb = S * SUB;
 	int lo = 0, hi = 31;
-	walk_order2(my, big, tb, lo, hi);
 	const bool valid = S >= 0 && S < nsub;
+	const bool produces = lane >= 1 && valid;
+	const unsigned *btok = w.brk_tok + (long)img * MAX_SEGS, *srefs = w.seg_refs + (long)img * MAX_SEGS;
+	unsigned tokbits;
+	unsigned long long rawbits;
+	const int qmet = walk_order2(my, big, tb, lo, hi, produces, btok, srefs, I.K, tokbits, rawbits);
 	int exitv = lo;
 	bool exit_known = lo == hi || !valid;
 	int o = 0;
@@ -1811,10 +1827,7 @@ __global__ __launch_bounds__(64 * GO_WAVES) void k_gorder(Work w)
 			atomicOr(w.slow + img, 1);
 		return;   // the exact pass takes the whole image
 	}
-	const bool produces = lane >= 1 && valid;
-	unsigned tokbits;
-	unsigned long long rawbits;
-	walk_bits(my, big, tb, o, produces, w.brk_tok + (long)img * MAX_SEGS, w.seg_refs + (long)img * MAX_SEGS, I.K, tokbits, rawbits);
+	walk_bits(my, big, tb, o, qmet, produces, btok, srefs, I.K, tokbits, rawbits);   // the tokens before the chains met
 	unsigned long long total;
 	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
 	if (produces) {
@@ -1963,9 +1976,9 @@ __device__ __forceinline__ void gorder_exact_body(const Work &w, unsigned *rows,
 	const long S = chunk * 64 + lane;
 	const int o = w.sublut[((img * w.NCS + chunk) * 64 + lane) * 32 + w.chunk_entry[img * w.NCS + chunk]];
 	const bool produces = S * SUB < T;
-	unsigned tokbits;
-	unsigned long long rawbits;
-	walk_bits(rows + lane * WROW, big, S * SUB, o, produces, w.brk_tok + (long)img * MAX_SEGS, w.seg_refs + (long)img * MAX_SEGS, I.K,
+	unsigned tokbits = 0;
+	unsigned long long rawbits = 0;
+	walk_bits(rows + lane * WROW, big, S * SUB, o, 16, produces, w.brk_tok + (long)img * MAX_SEGS, w.seg_refs + (long)img * MAX_SEGS, I.K,
 		tokbits, rawbits);
 	unsigned long long total;
 	const unsigned long long pre = wave_excl_scan64(produces ? tokbits + rawbits : 0ull, total);
