@@ -139,6 +139,33 @@ class Context:
         _check(self.lib.dwtx_transformation_inv(self.h, _ptr(out), _ptr(pyr), W, H, P), "dwtx_transformation_inv")
         return out
 
+    def transformation_fwd_pixels(self, pix, rings16=True, out=None):
+        """encode.c:155-159 in one pass as dwtx_encode_device runs it: uint8 [n,H,W,C] -> (int32 pyramid [n*C,H,W],
+        int16 planes [n*C,H,W] or None, mask of the ring levels that live in the int16 planes)."""
+        torch = self.torch
+        n, H, W, Cn = pix.shape
+        assert pix.dtype == torch.uint8 and pix.is_contiguous()
+        pyr, r16 = out if out is not None else (None, None)
+        if pyr is None:
+            pyr = torch.zeros((n * Cn, H, W), dtype=torch.int32, device=pix.device)
+        if rings16 and r16 is None:
+            r16 = torch.zeros((n * Cn, H, W), dtype=torch.int16, device=pix.device)
+        mask = C.c_uint(0)
+        _check(self.lib.dwtx_transformation_fwd_pixels(self.h, _ptr(pyr), _ptr(r16) if rings16 else None, C.byref(mask), _ptr(pix),
+                                                       W, H, Cn, n), "dwtx_transformation_fwd_pixels")
+        return pyr, (r16 if rings16 else None), mask.value
+
+    def transformation_inv_pixels(self, pyr, r16, mask, Cn, out=None):
+        """decode.c:258-264 as dwtx_decode_device runs it: (pyramid, int16 ring planes, mask) -> uint8 [n,H,W,C]."""
+        torch = self.torch
+        P, H, W = pyr.shape
+        n = P // Cn
+        if out is None:
+            out = torch.empty((n, H, W, Cn), dtype=torch.uint8, device=pyr.device)
+        _check(self.lib.dwtx_transformation_inv_pixels(self.h, _ptr(out), _ptr(pyr), _ptr(r16) if mask else None, mask, W, H, Cn, n),
+               "dwtx_transformation_inv_pixels")
+        return out
+
     def linearization(self, pyr):
         """encode.c:32 linearization: pyramid [P,H,W] -> Hilbert-linearised [P,H*W]."""
         torch = self.torch

@@ -42,6 +42,11 @@ int main(int argc, char **argv)
 	int W = (raw[2] | (raw[3] << 8)) + 1, H = (raw[4] | (raw[5] << 8)) + 1, C = raw[1] == '6' ? 3 : 1;
 	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)                           /* decode.c:158 */
 		return 1;
+	if (W > DWTX_MAX_SIDE || H > DWTX_MAX_SIDE) {
+		/* the reference goes on and skips the finest level (int overflow at decode.c:47): nothing to match */
+		fprintf(stderr, "image sides above %d are not supported (%dx%d)\n", DWTX_MAX_SIDE, W, H);
+		return 1;
+	}
 	int pixels_max = -1;
 	if (argc >= 4) {                                                    /* decode.c:165-166 */
 		pixels_max = atoi(argv[3]);

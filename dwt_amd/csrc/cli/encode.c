@@ -23,6 +23,11 @@ int main(int argc, char **argv)
 		return 1;
 	if (W < DWTX_MIN_LEN || H < DWTX_MIN_LEN)    /* encode.c:145 */
 		return 1;
+	if (W > DWTX_MAX_SIDE || H > DWTX_MAX_SIDE) {
+		/* the reference goes on and writes a stream that does not decode to the picture (int overflow at encode.c:45) */
+		fprintf(stderr, "image sides above %d are not supported (%dx%d)\n", DWTX_MAX_SIDE, W, H);
+		return 1;
+	}
 	long capacity = argc >= 4 ? atoi(argv[3]) : 0;   /* encode.c:150-152 */
 	dwtx_ctx *ctx;
 	if (dwtx_ctx_create(0, &ctx)) {

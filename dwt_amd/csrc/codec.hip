@@ -64,6 +64,52 @@ static int encode_part(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, int H, int 
 	return dwtx_encode_planes_ex(ctx, a, b, sq, hist_levels, W, H, C, n, capacity, dev_out, out_stride, dev_info, fine16);   // encode.c:163-221
 }
 
+// The pipelines' transforms on their own (include/dwtx.h): what encode_part / dwtx_decode_device's `finish` run around the
+// entropy stage, with the tiles' histograms riding along in the forward direction as they do there.
+extern "C" int dwtx_transformation_fwd_pixels(dwtx_ctx *ctx, int32_t *dev_pyr, int16_t *dev_rings16, unsigned *levels16,
+	const uint8_t *dev_pix, int W, int H, int C, int n)
+{
+	if (!ctx || !dev_pyr || !dev_pix || (C != 1 && C != 3) || n < 1 || (dev_rings16 && !levels16))
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	DWTX_CHECK_DIMS(W, H);
+	if (levels16)
+		*levels16 = 0u;
+	if (!dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C)) {
+		dwtx_set_error("the pixel transforms need W %% 4 == 0, more than 64 pixels on a side and 4-byte aligned pixels (%dx%d)", W, H);
+		return DWTX_ERR_ARG;
+	}
+	int rc;
+	dwtx_hist_sink sink;
+	unsigned hist_levels = 0;
+	if ((rc = dwtx_hist_begin(ctx, W, H, C, n, &sink)))
+		return rc;
+	dwtx_p16 fine16 = { nullptr, 0u };
+	const unsigned sq = dwtx_square_levels(W, H);
+	if (dev_rings16 && sq && (fine16.levels = dwtx_levels16(W, H, sq, 5)))
+		fine16.planes = dev_rings16;
+	if (levels16)
+		*levels16 = fine16.planes ? fine16.levels : 0u;
+	return dwtx_fwd_pixels8_hist(ctx, dev_pyr, dev_pix, W, H, C, n, &sink, &hist_levels, fine16);
+}
+
+extern "C" int dwtx_transformation_inv_pixels(dwtx_ctx *ctx, uint8_t *dev_pix, const int32_t *dev_pyr, const int16_t *dev_rings16,
+	unsigned levels16, int W, int H, int C, int n)
+{
+	if (!ctx || !dev_pyr || !dev_pix || (C != 1 && C != 3) || n < 1 || (levels16 && !dev_rings16))
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	DWTX_CHECK_DIMS(W, H);
+	if (!dwtx_gray8_ok(W, H, dev_pix, (size_t)W * H * C)) {
+		dwtx_set_error("the pixel transforms need W %% 4 == 0, more than 64 pixels on a side and 4-byte aligned pixels (%dx%d)", W, H);
+		return DWTX_ERR_ARG;
+	}
+	if (levels16 && levels16 != dwtx_levels16(W, H, dwtx_square_levels(W, H), 5))
+		return DWTX_ERR_ARG;   // (the mask the forward call reported for this geometry, or none)
+	const dwtx_p16 f16 = { levels16 ? const_cast<int16_t *>(dev_rings16) : nullptr, levels16 };
+	return dwtx_inv_pixels8(ctx, dev_pix, (size_t)W * H * C, dev_pyr, W, H, C, n, &f16);
+}
+
 // pixels (device) -> streams (device); async on the context's stream.
 // The transform is bound by memory, the entropy stage by vector-instruction issue: a batch runs as parts on streams of
 // their own, staggered so that part k's transform runs beside part k-1's entropy stage (the transforms follow one

@@ -87,16 +87,17 @@ void *dwtx_scratch(dwtx_ctx *ctx, int slot, size_t bytes);
 
 static inline int dwtx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Image sizes the kernels' int indices support: the reference itself indexes with int
-// (encode.c:40 `channels*(width*y+x)`), here one plane (W*H) must stay below 2^31.
+// Image sizes: sides of 8..DWTX_MAX_SIDE (above it the reference's own arithmetic overflows, include/dwtx.h), and the
+// kernels' int indices want one plane (W*H) below 2^31 — which 32768 x 32768 = 2^30 always is; the check stays for
+// whoever raises DWTX_MAX_SIDE (the reference itself indexes with int, encode.c:40 `channels*(width*y+x)`).
 static inline bool dwtx_dims_ok(int W, int H)
 {
-	return W >= DWTX_MIN_LEN && H >= DWTX_MIN_LEN && W <= 65536 && H <= 65536 && (long)W * H <= 0x7fffffffL - 4096;
+	return W >= DWTX_MIN_LEN && H >= DWTX_MIN_LEN && W <= DWTX_MAX_SIDE && H <= DWTX_MAX_SIDE && (long)W * H <= 0x7fffffffL - 4096;
 }
 #define DWTX_CHECK_DIMS(W, H)                                                              \
 	do {                                                                                    \
 		if (!dwtx_dims_ok(W, H)) {                                                          \
-			dwtx_set_error("unsupported image size %dx%d (8..65536 per side, W*H < 2^31)", W, H); \
+			dwtx_set_error("unsupported image size %dx%d (8..%d per side)", W, H, DWTX_MAX_SIDE); \
 			return DWTX_ERR_ARG;                                                            \
 		}                                                                                   \
 	} while (0)

@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <new>
+#include <vector>
 
 namespace {
 
@@ -305,16 +307,19 @@ struct dwtx_linplan {
 	dwtx_linplan *next;
 };
 
-static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
+static void plan_destroy(dwtx_linplan *p)
 {
-	for (dwtx_linplan *p = ctx->plans; p; p = p->next)
-		if (p->W == W && p->H == H) {
-			*out = p;
-			return DWTX_OK;
-		}
-	dwtx_linplan *p = (dwtx_linplan *)calloc(1, sizeof(*p));
-	if (!p)
-		return DWTX_ERR_NOMEM;
+	(void)hipFree(p->d_blockbase);
+	(void)hipFree(const_cast<int *>(p->tiles.base));
+	(void)hipFree(p->d_copy_list);
+	(void)hipFree(const_cast<int *>(p->tiles.xy2tile));
+	free(p);
+}
+
+// Fills a zero-initialised plan; on failure the caller destroys it (plan_destroy frees whatever was allocated so far).
+// Host temporaries are std::vectors: every return path gives them back.
+static int build_plan(dwtx_ctx *ctx, dwtx_linplan *p, int W, int H)
+{
 	p->W = W;
 	p->H = H;
 	LinGeom &g = p->g;
@@ -335,7 +340,6 @@ static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
 	g.blk_first[g.levels] = nb;
 	p->nblocks = nb;
 	if (hipMalloc((void **)&p->d_blockbase, sizeof(int) * (size_t)(nb > 0 ? nb : 1)) != hipSuccess) {
-		free(p);
 		dwtx_set_error("plan hipMalloc failed");
 		return DWTX_ERR_NOMEM;
 	}
@@ -344,155 +348,151 @@ static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {
 		dwtx_set_error("plan kernels -> %s", hipGetErrorString(e));
-		(void)hipFree(p->d_blockbase);
-		free(p);
 		return DWTX_ERR_DEVICE;
 	}
 	// the tile table: every non-empty block, level by level (built on the host once per geometry)
+	std::vector<int> hb((size_t)(nb > 0 ? nb : 1));
+	if (hipMemcpyAsync(hb.data(), p->d_blockbase, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+		hipStreamSynchronize(ctx->stream) != hipSuccess) {
+		dwtx_set_error("plan download failed");
+		return DWTX_ERR_DEVICE;
+	}
+	// points of block bb that lie inside its level's ring
+	auto in_ring = [&](int l, int bb) {
+		const int last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
+		return (bb + 1 < last ? hb[(size_t)bb + 1] : ring) - hb[(size_t)bb];
+	};
+	int nt = 0;
+	for (int l = 0; l < g.levels; ++l)
+		for (int bb = g.blk_first[l]; bb < g.blk_first[l + 1]; ++bb)
+			nt += in_ring(l, bb) > 0;
 	{
-		int *hb = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
-		if (!hb || hipMemcpyAsync(hb, p->d_blockbase, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-			hipStreamSynchronize(ctx->stream) != hipSuccess) {
-			free(hb);
-			(void)hipFree(p->d_blockbase);
-			free(p);
-			dwtx_set_error("plan download failed");
+		const size_t o_blk = sizeof(int) * (size_t)nt, o_cnt = 2 * sizeof(int) * (size_t)nt;
+		const size_t bytes = o_cnt + sizeof(unsigned short) * (size_t)nt + 64;
+		std::vector<char> host(bytes);
+		int *tb = (int *)host.data(), *tk = (int *)(host.data() + o_blk);
+		unsigned short *tc = (unsigned short *)(host.data() + o_cnt);
+		int t = 0;
+		for (int l = 0; l < g.levels; ++l) {
+			p->tiles.tile_first[l] = t;
+			for (int bb = g.blk_first[l]; bb < g.blk_first[l + 1]; ++bb) {
+				const int c = in_ring(l, bb);
+				if (c <= 0)
+					continue;
+				tb[t] = hb[(size_t)bb];
+				tk[t] = bb - g.blk_first[l];
+				tc[t] = (unsigned short)c;
+				++t;
+			}
+		}
+		p->tiles.tile_first[g.levels] = t;
+		p->tiles.NT = t;
+		char *dev = nullptr;
+		if (hipMalloc((void **)&dev, bytes) != hipSuccess) {
+			dwtx_set_error("tile table hipMalloc failed");
+			return DWTX_ERR_NOMEM;
+		}
+		p->tiles.base = (const int *)dev;   // (plan_destroy frees the one allocation through this pointer)
+		p->tiles.blk = (const int *)(dev + o_blk);
+		p->tiles.cnt = (const unsigned short *)(dev + o_cnt);
+		if (hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+			dwtx_set_error("tile table upload failed");
 			return DWTX_ERR_DEVICE;
 		}
-		int nt = 0;
-		for (int pass = 0; pass < 2; ++pass) {
-			int *tb = nullptr, *tk = nullptr;
-			unsigned short *tc = nullptr;
-			char *host = nullptr;
-			size_t o_cnt = 0, o_blk = 0, bytes = 0;
-			if (pass) {
-				o_blk = sizeof(int) * (size_t)nt;
-				o_cnt = 2 * sizeof(int) * (size_t)nt;
-				bytes = o_cnt + sizeof(unsigned short) * (size_t)nt + 64;
-				host = (char *)malloc(bytes);
-				if (!host) {
-					free(hb);
-					return DWTX_ERR_NOMEM;
-				}
-				tb = (int *)host;
-				tk = (int *)(host + o_blk);
-				tc = (unsigned short *)(host + o_cnt);
-			}
-			int t = 0;
-			for (int l = 0; l < g.levels; ++l) {
-				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
-				if (pass)
-					p->tiles.tile_first[l] = t;
-				for (int bb = first; bb < last; ++bb) {
-					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
-					if (c <= 0)
-						continue;
-					if (pass) {
-						tb[t] = hb[bb];
-						tk[t] = bb - first;
-						tc[t] = (unsigned short)c;
-					}
-					++t;
-				}
-			}
-			if (!pass) {
-				nt = t;
+	}
+	{
+		// block coordinates -> tile (for the forward transform's histograms): hilbert.h:15-34 at block granularity
+		int total = 0;
+		for (int l = 0; l < g.levels; ++l) {
+			p->tiles.xy_first[l] = total;
+			p->tiles.nbs[l] = g.lengths[l + 1] >= 64 ? g.lengths[l + 1] >> BLK_LOG2 : 0;
+			total += p->tiles.nbs[l] * p->tiles.nbs[l];
+		}
+		p->tiles.xy_first[g.levels] = total;
+		std::vector<int> tab((size_t)(total > 0 ? total : 1));
+		for (int l = 0; l < g.levels; ++l) {
+			const int nbs = p->tiles.nbs[l];
+			if (!nbs)
 				continue;
-			}
-			p->tiles.tile_first[g.levels] = t;
-			p->tiles.NT = t;
-			char *dev = nullptr;
-			if (hipMalloc((void **)&dev, bytes) != hipSuccess || hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-				free(host);
-				free(hb);
-				dwtx_set_error("tile table upload failed");
-				return DWTX_ERR_NOMEM;
-			}
-			p->tiles.base = (const int *)dev;
-			p->tiles.blk = (const int *)(dev + o_blk);
-			p->tiles.cnt = (const unsigned short *)(dev + o_cnt);
-			free(host);
-		}
-		{
-			// block coordinates -> tile (for the forward transform's histograms): hilbert.h:15-34 at block granularity
-			int total = 0;
-			for (int l = 0; l < g.levels; ++l) {
-				p->tiles.xy_first[l] = total;
-				p->tiles.nbs[l] = g.lengths[l + 1] >= 64 ? g.lengths[l + 1] >> BLK_LOG2 : 0;
-				total += p->tiles.nbs[l] * p->tiles.nbs[l];
-			}
-			p->tiles.xy_first[g.levels] = total;
-			int *tab = (int *)malloc(sizeof(int) * (size_t)(total > 0 ? total : 1));
-			if (!tab) {
-				free(hb);
-				return DWTX_ERR_NOMEM;
-			}
-			for (int l = 0; l < g.levels; ++l) {
-				const int nbs = p->tiles.nbs[l];
-				if (!nbs)
-					continue;
-				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
-				int t = p->tiles.tile_first[l];
-				for (int bb = first; bb < last; ++bb) {
-					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
-					unsigned x = 0, y = 0, d = (unsigned)(bb - first);   // the block's place on the nbs x nbs grid
-					for (unsigned sd = 1; sd < (unsigned)nbs; sd <<= 1) {
-						const unsigned rx = (d >> 1) & 1u, ry = (d ^ rx) & 1u;
-						if (rx && !ry) {
-							x ^= sd - 1;
-							y ^= sd - 1;
-						}
-						if (!ry) {
-							const unsigned tmp = x;
-							x = y;
-							y = tmp;
-						}
-						x |= rx ? sd : 0u;
-						y |= ry ? sd : 0u;
-						d >>= 2;
+			const int first = g.blk_first[l], last = g.blk_first[l + 1];
+			int t = p->tiles.tile_first[l];
+			for (int bb = first; bb < last; ++bb) {
+				const int c = in_ring(l, bb);
+				unsigned x = 0, y = 0, d = (unsigned)(bb - first);   // the block's place on the nbs x nbs grid
+				for (unsigned sd = 1; sd < (unsigned)nbs; sd <<= 1) {
+					const unsigned rx = (d >> 1) & 1u, ry = (d ^ rx) & 1u;
+					if (rx && !ry) {
+						x ^= sd - 1;
+						y ^= sd - 1;
 					}
-					tab[p->tiles.xy_first[l] + (int)y * nbs + (int)x] = c > 0 ? t++ : -1;
+					if (!ry) {
+						const unsigned tmp = x;
+						x = y;
+						y = tmp;
+					}
+					x |= rx ? sd : 0u;
+					y |= ry ? sd : 0u;
+					d >>= 2;
 				}
+				tab[(size_t)p->tiles.xy_first[l] + (size_t)y * nbs + x] = c > 0 ? t++ : -1;
 			}
-			int *dtab = nullptr;
-			if (hipMalloc((void **)&dtab, sizeof(int) * (size_t)(total > 0 ? total : 1)) != hipSuccess ||
-				hipMemcpy(dtab, tab, sizeof(int) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess) {
-				free(tab);
-				free(hb);
-				dwtx_set_error("block table upload failed");
-				return DWTX_ERR_NOMEM;
-			}
-			p->tiles.xy2tile = dtab;
-			free(tab);
 		}
-		{
-			const unsigned sq = dwtx_square_levels(W, H);
-			int *list = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
-			if (!list) {
-				free(hb);
-				return DWTX_ERR_NOMEM;
-			}
-			int m = 0;
-			for (int l = 0; l < g.levels; ++l) {
-				p->copy_upto[l] = m;
-				const int first = g.blk_first[l], last = g.blk_first[l + 1], ring = g.pixels[l + 1] - g.pixels[l];
-				for (int bb = first; bb < last; ++bb) {
-					const int c = (bb + 1 < last ? hb[bb + 1] : ring) - hb[bb];
-					if (c > 0 && !(((sq >> l) & 1u) && c == (1 << g.blk_pts_log2[l])))
-						list[m++] = bb;
-				}
-			}
-			p->copy_upto[g.levels] = m;
-			if (hipMalloc((void **)&p->d_copy_list, sizeof(int) * (size_t)(m > 0 ? m : 1)) != hipSuccess ||
-				hipMemcpy(p->d_copy_list, list, sizeof(int) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) {
-				free(list);
-				free(hb);
-				dwtx_set_error("copy list upload failed");
-				return DWTX_ERR_NOMEM;
-			}
-			free(list);
+		int *dtab = nullptr;
+		if (hipMalloc((void **)&dtab, sizeof(int) * tab.size()) != hipSuccess) {
+			dwtx_set_error("block table hipMalloc failed");
+			return DWTX_ERR_NOMEM;
 		}
-		free(hb);
+		p->tiles.xy2tile = dtab;
+		if (hipMemcpy(dtab, tab.data(), sizeof(int) * (size_t)total, hipMemcpyHostToDevice) != hipSuccess) {
+			dwtx_set_error("block table upload failed");
+			return DWTX_ERR_DEVICE;
+		}
+	}
+	{
+		const unsigned sq = dwtx_square_levels(W, H);
+		std::vector<int> list((size_t)(nb > 0 ? nb : 1));
+		int m = 0;
+		for (int l = 0; l < g.levels; ++l) {
+			p->copy_upto[l] = m;
+			for (int bb = g.blk_first[l]; bb < g.blk_first[l + 1]; ++bb) {
+				const int c = in_ring(l, bb);
+				if (c > 0 && !(((sq >> l) & 1u) && c == (1 << g.blk_pts_log2[l])))
+					list[(size_t)m++] = bb;
+			}
+		}
+		p->copy_upto[g.levels] = m;
+		if (hipMalloc((void **)&p->d_copy_list, sizeof(int) * (size_t)(m > 0 ? m : 1)) != hipSuccess) {
+			dwtx_set_error("copy list hipMalloc failed");
+			return DWTX_ERR_NOMEM;
+		}
+		if (hipMemcpy(p->d_copy_list, list.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess) {
+			dwtx_set_error("copy list upload failed");
+			return DWTX_ERR_DEVICE;
+		}
+	}
+	return DWTX_OK;
+}
+
+static int get_plan(dwtx_ctx *ctx, int W, int H, dwtx_linplan **out)
+{
+	for (dwtx_linplan *p = ctx->plans; p; p = p->next)
+		if (p->W == W && p->H == H) {
+			*out = p;
+			return DWTX_OK;
+		}
+	dwtx_linplan *p = (dwtx_linplan *)calloc(1, sizeof(*p));
+	if (!p)
+		return DWTX_ERR_NOMEM;
+	int rc;
+	try {
+		rc = build_plan(ctx, p, W, H);
+	} catch (const std::bad_alloc &) {
+		dwtx_set_error("plan tables: out of host memory");
+		rc = DWTX_ERR_NOMEM;
+	}
+	if (rc) {
+		plan_destroy(p);   // not linked into ctx->plans yet: nobody else would free it
+		return rc;
 	}
 	p->next = ctx->plans;
 	ctx->plans = p;
@@ -515,11 +515,7 @@ void dwtx_free_plans(dwtx_ctx *ctx)
 	dwtx_linplan *p = ctx->plans;
 	while (p) {
 		dwtx_linplan *n = p->next;
-		(void)hipFree(p->d_blockbase);
-		(void)hipFree(const_cast<int *>(p->tiles.base));
-		(void)hipFree(p->d_copy_list);
-		(void)hipFree(const_cast<int *>(p->tiles.xy2tile));
-		free(p);
+		plan_destroy(p);
 		p = n;
 	}
 	ctx->plans = nullptr;
@@ -574,8 +570,9 @@ extern "C" int dwtx_linearization(dwtx_ctx *ctx, int32_t *lin, const int32_t *py
 int dwtx_linearization_ex(dwtx_ctx *ctx, int32_t *lin, const int32_t *pyr, int W, int H, int nplanes, unsigned skip_levels,
 	dwtx_p16 p16)
 {
-	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || nplanes < 1 || nplanes > 65535)
+	if (!ctx || !lin || !pyr || nplanes < 1 || nplanes > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	DWTX_ENTER(ctx);
 	dwtx_linplan *p;
 	int rc = get_plan(ctx, W, H, &p);
@@ -608,8 +605,9 @@ extern "C" int dwtx_reconstruction(dwtx_ctx *ctx, int32_t *pyr, const int32_t *l
 int dwtx_reconstruction_ex(dwtx_ctx *ctx, int32_t *pyr, const int32_t *lin, const int *dev_missing,
 	int levels_out, int W, int H, int C, int n, unsigned skip_levels, dwtx_p16 p16)
 {
-	if (!ctx || !lin || !pyr || W < DWTX_MIN_LEN || H < DWTX_MIN_LEN || (C != 1 && C != 3) || n < 1 || n * C > 65535)
+	if (!ctx || !lin || !pyr || (C != 1 && C != 3) || n < 1 || n * C > 65535)
 		return DWTX_ERR_ARG;
+	DWTX_CHECK_DIMS(W, H);
 	DWTX_ENTER(ctx);
 	dwtx_linplan *p;
 	int rc = get_plan(ctx, W, H, &p);

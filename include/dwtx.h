@@ -40,6 +40,12 @@ extern "C" {
 
 #define DWTX_MAX_LEVELS 16
 #define DWTX_MIN_LEN     8     /* encode.c:144, decode.c:157 */
+/* Largest image side.  encode.c:140 lets sides up to 65536 through, but above 32768 the finest level's Hilbert square is
+ * 65536 wide and encode.c:45 / decode.c:47 compute `lengths[l+1] * lengths[l+1]` in int: it wraps to 0, the finest ring
+ * is never visited and the reference binary writes a stream its own decoder does not turn back into the picture.  There
+ * is nothing to be bit-exact with beyond this side, so every entry point refuses it (DWTX_ERR_ARG; the CLIs exit 1 with
+ * a message) — a documented difference, DESIGN.md section 7. */
+#define DWTX_MAX_SIDE    32768
 
 typedef struct dwtx_ctx dwtx_ctx;
 
@@ -197,6 +203,19 @@ int dwtx_pixels_from_planes(dwtx_ctx *ctx, uint8_t *dev_pix, const int32_t *dev_
 int dwtx_transformation_fwd(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_in, int W, int H, int nplanes);
 /* decode.c:16-30 transformation(): inverse.  dev_in (pyramid) is preserved. */
 int dwtx_transformation_inv(dwtx_ctx *ctx, int32_t *dev_out, const int32_t *dev_in, int W, int H, int nplanes);
+
+/* The same two transforms as the whole-image pipelines run them when the pictures are 8-bit pixels with W % 4 == 0 and more
+ * than 64 pixels on a side (else DWTX_ERR_ARG: use the two calls above): encode.c:155-159 — widening, ycocg_from_rgb and
+ * transformation() — in one pass over interleaved pixels [n][H][W][C], the finest level in packed 16-bit arithmetic; and
+ * decode.c:258-264 — transformation(), rgb_from_ycocg with its clamps and write_pnm's clamp.  The detail rings of the up to
+ * five finest levels (those in *levels16 / levels16, bit l = ring level l) are kept as int16 in dev_rings16 [n*C][H][W] —
+ * same positions and pitch as in the pyramid, whose positions for those rings are then not touched; results are the
+ * int32 transform's (an 8-bit source cannot leave 16 bits there: DESIGN.md section 4.1).  dev_rings16 == NULL: everything
+ * in dev_pyr [n*C][H][W] int32.  What bench.py's `roofline_codec` times. */
+int dwtx_transformation_fwd_pixels(dwtx_ctx *ctx, int32_t *dev_pyr, int16_t *dev_rings16, unsigned *levels16,
+	const uint8_t *dev_pix, int W, int H, int C, int n);
+int dwtx_transformation_inv_pixels(dwtx_ctx *ctx, uint8_t *dev_pix, const int32_t *dev_pyr, const int16_t *dev_rings16,
+	unsigned levels16, int W, int H, int C, int n);
 
 /* encode.c:32-58 linearization(): Mallat pyramid planes [nplanes][H][W] ->
  * Hilbert-linearised planes [nplanes][W*H] (root raster first, then the detail

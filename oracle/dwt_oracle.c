@@ -244,6 +244,28 @@ static int in_ring(const orc_geom *g, int l, int x, int y)
 	return x < g->widths[l + 1] && y < g->heights[l + 1] && (x >= g->widths[l] || y >= g->heights[l]);
 }
 
+/* The curve visits every aligned s*s square (s a power of two) on s*s consecutive indices starting at a multiple
+ * of s*s.  A square that holds no point of ring l — wholly outside the level's w*h rectangle, or wholly inside the
+ * LL quadrant — contributes nothing to the loops of encode.c:45-56 / decode.c:47-63, so those indices can be stepped
+ * over in one go; the points that ARE visited come in the reference's order.  (The reference walks all n*n indices:
+ * minutes for a thin 32768-wide frame; this keeps such frames testable.)  Returns how many indices from d on are
+ * known to be empty (0: look at d itself). */
+static long empty_span(const orc_geom *g, int l, int n, long d)
+{
+	for (int s = n; s >= 8; s >>= 1) {
+		long ss = (long)s * s;
+		if (d & (ss - 1))
+			continue;
+		int x, y;
+		orc_hilbert(n, (int)d, &x, &y);
+		x &= ~(s - 1);
+		y &= ~(s - 1);
+		if (x >= g->widths[l + 1] || y >= g->heights[l + 1] || (x + s <= g->widths[l] && y + s <= g->heights[l]))
+			return ss;
+	}
+	return 0;
+}
+
 /* encode.c:32-58 */
 void orc_linearize(int *lin, const int *pyr, const orc_geom *g, int C)
 {
@@ -259,6 +281,13 @@ void orc_linearize(int *lin, const int *pyr, const orc_geom *g, int C)
 		int n = g->lengths[l + 1];
 		long nn = (long)n * n;
 		for (long d = 0; d < nn; ++d) {
+			if (!(d & 63)) {
+				long skip = empty_span(g, l, n, d);
+				if (skip) {
+					d += skip - 1;
+					continue;
+				}
+			}
 			int x, y;
 			orc_hilbert(n, (int)d, &x, &y);
 			if (!in_ring(g, l, x, y))
@@ -284,6 +313,13 @@ void orc_reconstruct(int *pyr, int *const *lin, const int *missing, const orc_ge
 		int n = g->lengths[l + 1];
 		long nn = (long)n * n;
 		for (long d = 0; d < nn; ++d) {
+			if (!(d & 63)) {
+				long skip = empty_span(g, l, n, d);
+				if (skip) {
+					d += skip - 1;
+					continue;
+				}
+			}
 			int x, y;
 			orc_hilbert(n, (int)d, &x, &y);
 			if (!in_ring(g, l, x, y))
@@ -471,7 +507,7 @@ static int *pixels_to_coefs(const uint8_t *pix, int W, int H, int C)
 
 int orc_stage_dump(const uint8_t *pix, int W, int H, int C, int *coef, int *lin, int *planes)
 {
-	if (W < 8 || H < 8 || W > 65536 || H > 65536 || (C != 1 && C != 3))
+	if (W < 8 || H < 8 || W > ORC_MAX_SIDE || H > ORC_MAX_SIDE || (C != 1 && C != 3))
 		return 1;
 	orc_geom g;
 	orc_geometry(&g, W, H, 8);
@@ -503,7 +539,7 @@ int orc_stage_dump(const uint8_t *pix, int W, int H, int C, int *coef, int *lin,
 int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 	uint8_t **out, size_t *out_len, orc_stats *st)
 {
-	if (W < 8 || H < 8 || W > 65536 || H > 65536 || (C != 1 && C != 3))
+	if (W < 8 || H < 8 || W > ORC_MAX_SIDE || H > ORC_MAX_SIDE || (C != 1 && C != 3))
 		return 1;                                   /* encode.c:140-146 */
 	orc_geom g;
 	orc_geometry(&g, W, H, 8);
@@ -522,7 +558,7 @@ int orc_encode(const uint8_t *pix, int W, int H, int C, long capacity,
 int orc_encode_lin(const int *lin, int W, int H, int C, long capacity,
 	uint8_t **out, size_t *out_len, orc_stats *st)
 {
-	if (W < 8 || H < 8 || W > 65536 || H > 65536 || (C != 1 && C != 3))
+	if (W < 8 || H < 8 || W > ORC_MAX_SIDE || H > ORC_MAX_SIDE || (C != 1 && C != 3))
 		return 1;
 	orc_geom g;
 	int levels = orc_geometry(&g, W, H, 8);
@@ -755,8 +791,8 @@ static int decode_entropy(const uint8_t *dwt, size_t len, long pixels_max,
 	int C = dwt[1] == '6' ? 3 : 1;
 	int W = (dwt[2] | (dwt[3] << 8)) + 1;
 	int H = (dwt[4] | (dwt[5] << 8)) + 1;
-	if (W < 8 || H < 8)
-		return 1;
+	if (W < 8 || H < 8 || W > ORC_MAX_SIDE || H > ORC_MAX_SIDE)
+		return 1;                                              /* see ORC_MAX_SIDE in dwt_oracle.h */
 	int levels = orc_geometry(g, W, H, 8);
 	int levels_max = levels;
 	if (pixels_max >= 0)                                       /* decode.c:165-171 */

@@ -23,6 +23,13 @@ extern "C" {
 #endif
 
 #define ORC_MAX_LEVELS 16
+/* Largest side the oracle (and the product) accepts.  encode.c:140 lets sides up to 65536 through, but for a side above
+ * 32768 the finest level's Hilbert square is 65536 wide and encode.c:45 / decode.c:47 compute `lengths * lengths` in
+ * int: the product wraps to 0, the finest ring is never visited, and the reference binary writes a stream that its own
+ * decoder does not turn back into the picture (pinned in tests/test_oracle.py).  "What the reference computes" is
+ * therefore only defined up to 32768 per side; above that both the oracle and the library refuse (return 1 /
+ * DWTX_ERR_ARG) — the second documented difference, DESIGN.md section 7. */
+#define ORC_MAX_SIDE 32768
 
 /* Level geometry (utils.h:17-40).  Index 0 = root LL, index `levels` = full image. */
 typedef struct {

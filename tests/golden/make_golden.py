@@ -42,6 +42,16 @@ CASES = [
     ("c1920x1080_cap65536", 1920, 1080, 3, 0, 0, 65536, None),
     ("c4096x4096", 4096, 4096, 3, 0, 0, 0, None),          # one frame of BASELINE.json configs[4]
     ("c4096x4096_px70000", 4096, 4096, 3, 0, 0, 0, 70000),
+    # sides in (16384, 32768]: the largest the reference's own arithmetic is defined for (above 32768 encode.c:45's
+    # `lengths * lengths` wraps to 0 in int, see ORC_MAX_SIDE).  The reference walks 2^30 curve indices per level for these:
+    # about half a minute each way.
+    ("g32768x8", 32768, 8, 1, 21, 0, 0, None),
+    ("c20001x9", 20001, 9, 3, 22, 0, 0, None),
+    ("c8x32768", 8, 32768, 3, 23, 0, 0, None),
+    ("g32768x40_cap50000", 32768, 40, 1, 24, 0, 50000, None),
+    ("g16388x24_noise", 16388, 24, 1, 25, 1, 0, None),
+    ("g20000x600", 20000, 600, 1, 26, 0, 0, None),
+    ("c32764x12_px100000", 32764, 12, 3, 27, 0, 0, 100000),
 ]
 # BASELINE.json configs[3]: ~3 minutes and ~10 GB of RAM with the reference; only with DWT_GOLDEN_HEAVY=1
 HEAVY = [("c16384x16384_cap1MiB", 16384, 16384, 3, 0, 0, 1048576, None)]
@@ -61,6 +71,11 @@ def main():
         old = {}
         if os.path.exists(os.path.join(HERE, "golden.json")):
             old = json.load(open(os.path.join(HERE, "golden.json")))
+        only = set(sys.argv[1:])   # `make_golden.py name …`: (re)make only these records, keep the others as they are
+        if only:
+            assert only <= {c[0] for c in cases}, "unknown case name"
+            out.update({k: v for k, v in old.items() if k not in only})
+            cases = [c for c in cases if c[0] in only]
         for name in [h[0] for h in HEAVY]:
             if name in old and os.environ.get("DWT_GOLDEN_HEAVY") != "1":
                 out[name] = old[name]   # keep the heavy record from an earlier run

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("wh", [(8, 8), (320, 240), (1920, 1080), (4096, 4096), (16384, 16384), (131, 77),
-                                (17, 300), (65536, 9), (9, 65536)])
+                                (17, 300), (65536, 9), (9, 65536), (32768, 9), (9, 32768), (32768, 32768), (20001, 9)])
 def test_compute_lengths_matches_oracle(wh):
     import dwt_amd
 

@@ -326,3 +326,25 @@ def test_a_stream_that_claims_more_than_16_bit_planes_is_refused_with_a_message(
     assert r.returncode == 1 and b"more than 16 bit planes" in r.stderr and not os.path.exists(pnm)
     if orc.have_ref():
         assert run(os.path.join(orc.REF_DIR, "decode"), dwt, ref_pnm).returncode == 0 and os.path.exists(ref_pnm)
+
+
+def test_sides_above_32768_are_refused_with_a_message(tmp_path):
+    """The second documented difference: encode.c:140 lets sides up to 65536 through and then overflows at encode.c:45
+    (the stream the reference writes does not decode to the picture: tests/test_oracle.py); bin/encode and bin/decode
+    say so and exit 1 without writing anything."""
+    pix = orc.synth(32776, 8, 1, 5, 0)
+    src, dwt, pnm = str(tmp_path / "i.pnm"), str(tmp_path / "o.dwt"), str(tmp_path / "o.pnm")
+    orc.write_pnm(src, pix)
+    r = run(ENC, src, dwt)
+    assert r.returncode == 1 and b"sides above 32768 are not supported" in r.stderr and not os.path.exists(dwt)
+    if orc.have_ref():
+        ref = run(os.path.join(orc.REF_DIR, "encode"), src, dwt)
+        assert ref.returncode == 0 and os.path.exists(dwt)      # a stream that claims 32776x8 ...
+        r = run(DEC, dwt, pnm)                                    # ... which bin/decode refuses
+        assert r.returncode == 1 and b"sides above 32768 are not supported" in r.stderr and not os.path.exists(pnm)
+    # the largest side inside the fence works (bytes: golden g32768x8 in test_codec_gpu.py)
+    orc.write_pnm(src, orc.synth(32768, 8, 1, 5, 0))
+    r = run(ENC, src, dwt)
+    assert r.returncode == 0
+    r = run(DEC, dwt, pnm)
+    assert r.returncode == 0 and (orc.read_pnm(pnm) == orc.synth(32768, 8, 1, 5, 0)).all()

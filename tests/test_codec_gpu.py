@@ -355,16 +355,24 @@ def test_length_beyond_the_stream_stride_is_refused_or_clamped(ctx):
     assert (got[0, : want.size].cpu().numpy() == want.reshape(-1)).all()
 
 
-def test_image_sizes_beyond_int_indexing_are_refused(ctx):
-    """W*H >= 2^31 would overflow the int geometry (the reference's own int indexing, encode.c:40): a clean
-    argument error instead of a device fault."""
+def test_image_sizes_beyond_the_references_arithmetic_are_refused(ctx):
+    """Sides above 32768 (DWTX_MAX_SIDE): encode.c:45 / decode.c:47 overflow there and the reference binary's stream
+    does not decode to the picture (tests/test_oracle.py pins that) — a clean argument error from every entry point,
+    encode and decode, instead of bytes nobody can compare.  W*H >= 2^31 (encode.c:40) is inside that fence."""
     import torch
+
+    import dwt_amd
 
     tiny = torch.zeros(64, dtype=torch.uint8, device=ctx.device)
     info = torch.zeros(256, dtype=torch.uint8, device=ctx.device)
-    for W, H in ((50000, 50000), (65536, 32768), (65537, 8), (8, 7)):
+    for W, H in ((50000, 50000), (65536, 32768), (65537, 8), (8, 7), (32776, 8), (8, 32769), (32769, 32769)):
         rc = ctx.lib.dwtx_encode_device(ctx.h, tiny.data_ptr(), W, H, 1, 1, 0, tiny.data_ptr(), 64, info.data_ptr())
         assert rc == -3, (W, H, rc)
+        assert b"unsupported image size" in ctx.lib.dwtx_last_error()
+    # a stream whose header claims such a size (the reference's encoder writes them): refused, nothing decoded
+    head = bytes([ord("W"), ord("5"), (32776 - 1) & 255, (32776 - 1) >> 8, 7, 0])
+    with pytest.raises(RuntimeError, match="unsupported image size"):
+        ctx.decode(head + bytes(500))
 
 
 def test_config_c_1024_frames_of_1080p_rgb_in_one_call(ctx):

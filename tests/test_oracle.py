@@ -212,6 +212,47 @@ DAMAGED = [("damaged_order_beyond_31_47x650x1.dwt", 47, 650, 1, b""), ("damaged_
 
 
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("wh", [(32776, 8), (8, 32769), (40000, 9)])
+def test_sides_above_32768_what_the_reference_binary_does_and_the_oracle_refuses(tmp_path, wh):
+    """The second documented difference.  encode.c:140 accepts sides up to 65536, but above 32768
+    the finest level's curve square is 65536 wide and `lengths[l+1] * lengths[l+1]` (encode.c:45, decode.c:47) wraps to 0
+    in int: the reference binary returns 0 in no time, leaves the finest ring out of the stream and its own decoder does
+    not give the picture back.  The oracle (and the library, tests/test_codec_gpu.py / test_cli_gpu.py) refuse such sizes."""
+    W, H = wh
+    pix = orc.synth(W, H, 1, 5, 0)
+    src, dwt, dec = (str(tmp_path / n) for n in ("i.pnm", "o.dwt", "o.pnm"))
+    orc.write_pnm(src, pix)
+    r = subprocess.run([os.path.join(orc.REF_DIR, "encode"), src, dwt], capture_output=True, timeout=120)
+    assert r.returncode == 0
+    ref = open(dwt, "rb").read()
+    root_bits = int(r.stderr.decode().splitlines()[1].split()[0])
+    total_bits = int(r.stderr.decode().splitlines()[2].split()[0])
+    assert total_bits - root_bits < 200, "the reference coded the finest ring after all?"
+    r = subprocess.run([os.path.join(orc.REF_DIR, "decode"), dwt, dec], capture_output=True, timeout=120)
+    assert r.returncode == 0
+    back = orc.read_pnm(dec)
+    assert back.shape != pix.shape or not (back == pix).all(), "the reference round-trips this size after all?"
+    with pytest.raises(ValueError):
+        orc.encode(pix)
+    assert orc.decode(ref) is None
+
+
+@pytest.mark.parametrize("wh", [(32768, 8), (8, 32768)])
+def test_the_largest_side_against_reference_made_goldens_is_quick(wh):
+    """Sides of exactly 32768 are inside the range (goldens g32768x8 / c8x32768 come from the reference binary, which
+    walks 2^30 curve indices for them); the oracle steps over the curve's empty squares and takes a fraction of a second."""
+    import time
+
+    W, H = wh
+    pix = orc.synth(W, H, 1, 5, 0)
+    t0 = time.time()
+    data, _ = orc.encode(pix)
+    back = orc.decode(data)
+    assert time.time() - t0 < 20
+    assert back.shape == pix.shape and (back == pix).all()
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
 @pytest.mark.parametrize("case", DAMAGED)
 def test_damaged_streams_that_leave_the_range_of_the_shifts(tmp_path, case):
     """Two damaged streams a seeded sweep found (tools/fuzz_decode.py): in one the VLI order passes 31 (vli.h:90-91

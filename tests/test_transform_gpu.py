@@ -100,3 +100,45 @@ def test_small_inverse_root_only(ctx):
         want = np.stack([orc.inverse(a[p][:, :, None])[:, :, 0] for p in range(2)])
         got = ctx.transformation_inv(torch.from_numpy(a).cuda())
         assert (got.cpu().numpy() == want).all()
+
+
+def merge_rings(pyr, r16, mask, W, H):
+    """the pyramid as one int32 array: the ring levels in `mask` come from the 16-bit planes"""
+    g = orc.geometry(W, H)
+    out = pyr.copy()
+    for l in range(g.levels):
+        if (mask >> l) & 1:
+            w0, h0, w1, h1 = g.widths[l], g.heights[l], g.widths[l + 1], g.heights[l + 1]
+            out[:, :h1, w0:w1] = r16[:, :h1, w0:w1]
+            out[:, h0:h1, :w0] = r16[:, h0:h1, :w0]
+    return out
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 1), (96, 260, 3), (1080, 1920, 3), (67, 516, 1), (1024, 1024, 1), (540, 72, 3), (257, 1028, 3)])
+@pytest.mark.parametrize("rings16", [True, False])
+def test_pixel_transforms_as_the_pipelines_run_them(ctx, shape, rings16):
+    """dwtx_transformation_fwd_pixels / _inv_pixels (encode.c:155-159, decode.c:258-264 in one pass each, the finest rings
+    as 16-bit values): the pyramid is the oracle's, a noise picture with the largest steps an 8-bit source can make too,
+    and the inverse of the pyramid gives the pixels back."""
+    import torch
+
+    H, W, Cn = shape
+    rng = np.random.default_rng(W + H)
+    pix = np.stack([orc.synth(W, H, Cn, 4, 0), orc.synth(W, H, Cn, 5, 1), (rng.integers(0, 2, (H, W, Cn)) * 255).astype(np.uint8)])
+    t = torch.from_numpy(pix).cuda()
+    pyr, r16, mask = ctx.transformation_fwd_pixels(t, rings16=rings16)
+    assert rings16 or mask == 0
+    got = merge_rings(pyr.cpu().numpy(), r16.cpu().numpy() if r16 is not None else None, mask, W, H)
+    want = np.concatenate([to_planes(orc.stage_dump(p)[0]) for p in pix])
+    assert (got == want).all()
+    back = ctx.transformation_inv_pixels(pyr, r16, mask, Cn)
+    assert torch.equal(back, t)
+
+
+def test_pixel_transforms_refuse_shapes_their_kernels_do_not_take(ctx):
+    import torch
+
+    for H, W in ((100, 131), (64, 64), (40, 40)):
+        t = torch.zeros((1, H, W, 1), dtype=torch.uint8, device=ctx.device)
+        with pytest.raises(RuntimeError):
+            ctx.transformation_fwd_pixels(t)
