@@ -306,6 +306,18 @@ class Context:
         off = StreamInfo.nbytes.offset
         return info[:, off:off + 8].contiguous().view(self.torch.int64).view(-1)
 
+    def pack_streams(self, streams, lens, out, offsets=None):
+        """dwtx_pack_streams: the n streams of a batch (uint8 [n, stride], int64 lens on the device) moved together into the
+        flat uint8 tensor `out`, stream i at sum(round8(lens[:i])); offsets: optional int64 [n + 1] device tensor."""
+        torch = self.torch
+        n, stride = streams.shape
+        assert streams.dtype == torch.uint8 and streams.is_contiguous() and out.dtype == torch.uint8 and out.is_contiguous()
+        assert lens.dtype == torch.int64 and lens.numel() == n and lens.is_contiguous()
+        assert offsets is None or (offsets.dtype == torch.int64 and offsets.numel() == n + 1)
+        _check(self.lib.dwtx_pack_streams(self.h, _ptr(out), out.numel(), _ptr(offsets) if offsets is not None else None,
+                                          _ptr(streams), stride, _ptr(lens), n), "dwtx_pack_streams")
+        return out
+
     def decode_device(self, streams, lens, W, H, C_, levels_max=-1, out=None):
         """device streams [n,stride] + int64 lens -> (uint8 [n, W*H*C] pixels, list of DecodeInfo); syncs once."""
         torch = self.torch

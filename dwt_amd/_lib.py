@@ -98,6 +98,7 @@ SYMBOLS = {
     "dwtx_transformation_inv": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_transformation_fwd_pixels": (_i, [_vp, _vp, _vp, C.POINTER(C.c_uint), _vp, _i, _i, _i, _i]),
     "dwtx_transformation_inv_pixels": (_i, [_vp, _vp, _vp, _vp, C.c_uint, _i, _i, _i, _i]),
+    "dwtx_pack_streams": (_i, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _i]),
     "dwtx_linearization": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "dwtx_reconstruction": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dwtx_encode_bound": (_sz, [_i, _i, _i]),

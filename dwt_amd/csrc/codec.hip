@@ -140,9 +140,12 @@ extern "C" int dwtx_encode_device(dwtx_ctx *ctx, const uint8_t *dev_pix, int W, 
 	for (int k = 0; k < K && !rc; ++k) {
 		const int i0 = (int)((long)n * k / K), cnt = (int)((long)n * (k + 1) / K) - i0;
 		hipStream_t st = part[k]->stream;
-		DWTX_HIP(hipStreamWaitEvent(st, start, 0));
-		if (k)
-			DWTX_HIP(hipStreamWaitEvent(st, lifted[k - 1], 0));
+		// (a failure here must not leave the function: parts already queued read the caller's buffers, the join loop below waits for them)
+		if (hipStreamWaitEvent(st, start, 0) != hipSuccess || (k && hipStreamWaitEvent(st, lifted[k - 1], 0) != hipSuccess)) {
+			dwtx_set_error("%s:%d hipStreamWaitEvent failed for encoder part %d", __FILE__, __LINE__, k);
+			rc = DWTX_ERR_DEVICE;
+			break;
+		}
 		rc = encode_part(part[k], dev_pix + img_bytes * i0, W, H, C, cnt, capacity, dev_out + out_stride * (size_t)i0, out_stride,
 			dev_info + i0, lifted[k]);
 		if (hipEventRecord(done[k], st) != hipSuccess && !rc)
@@ -258,6 +261,67 @@ extern "C" int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, siz
 	using Part = decltype(part);
 	return dwtx_decode_planes_ex(ctx, a, b, dev_streams, stream_stride, dev_lens, W, H, C, n, levels_max, host_info,
 		[](void *user, int first, int count, unsigned fused) { return (*(Part *)user)(first, count, fused); }, &part, fine16);
+}
+
+// ---- dwtx_pack_streams: a step's streams as one message (include/dwtx.h) -------------------------------------------
+namespace {
+constexpr int PK_THREADS = 256;
+constexpr int PK_PIECE = 1 << 16;   // bytes of one stream a workgroup moves
+
+__device__ __forceinline__ unsigned long long pk_round8(unsigned long long len, unsigned long long stride)
+{
+	return ((len < stride ? len : stride) + 7ull) & ~7ull;
+}
+
+// grid (pieces of the longest possible stream, n): every workgroup adds up the rounded lengths before its stream
+// (n is a batch size: a few hundred 8-byte loads from L2) and moves its piece with 8-byte accesses — rows and offsets are
+// multiples of 8 bytes
+__global__ __launch_bounds__(PK_THREADS) void k_pack_streams(uint8_t *out, unsigned long long out_bytes, unsigned long long *offsets,
+	const uint8_t *streams, unsigned long long stride, const unsigned long long *lens, int n)
+{
+	__shared__ unsigned long long part[PK_THREADS / 64];
+	const int i = blockIdx.y;
+	unsigned long long mine = 0;
+	for (int j = threadIdx.x; j < i; j += PK_THREADS)
+		mine += pk_round8(lens[j], stride);
+	for (int o = 32; o; o >>= 1)
+		mine += __shfl_down(mine, o);
+	if ((threadIdx.x & 63) == 0)
+		part[threadIdx.x >> 6] = mine;
+	__syncthreads();
+	unsigned long long off = 0;
+	for (int k = 0; k < PK_THREADS / 64; ++k)
+		off += part[k];
+	const unsigned long long len8 = pk_round8(lens[i], stride);
+	if (offsets && blockIdx.x == 0 && threadIdx.x == 0) {
+		offsets[i] = off;
+		if (i == n - 1)
+			offsets[n] = off + len8;
+	}
+	const unsigned long long first = (unsigned long long)blockIdx.x * PK_PIECE;
+	if (first >= len8)
+		return;
+	const unsigned long long last = first + PK_PIECE < len8 ? first + PK_PIECE : len8;
+	const unsigned long long *src = reinterpret_cast<const unsigned long long *>(streams + (unsigned long long)i * stride);
+	unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + off);
+	for (unsigned long long b = first + 8ull * threadIdx.x; b < last; b += 8ull * PK_THREADS)
+		if (off + b + 8 <= out_bytes)
+			dst[b >> 3] = src[b >> 3];
+}
+} // namespace
+
+extern "C" int dwtx_pack_streams(dwtx_ctx *ctx, uint8_t *dev_out, size_t out_bytes, unsigned long long *dev_offsets,
+	const uint8_t *dev_streams, size_t stream_stride, const unsigned long long *dev_lens, int n)
+{
+	if (!ctx || !dev_out || !dev_streams || !dev_lens || n < 1 || n > 65535 || (stream_stride & 7) || !stream_stride ||
+		((uintptr_t)dev_out & 7) || ((uintptr_t)dev_streams & 7))
+		return DWTX_ERR_ARG;
+	DWTX_ENTER(ctx);
+	const unsigned pieces = (unsigned)((stream_stride + PK_PIECE - 1) / PK_PIECE);
+	hipLaunchKernelGGL(k_pack_streams, dim3(pieces, n), dim3(PK_THREADS), 0, ctx->stream, dev_out, (unsigned long long)out_bytes, dev_offsets,
+		dev_streams, (unsigned long long)stream_stride, dev_lens, n);
+	DWTX_LAUNCH_CHECK();
+	return DWTX_OK;
 }
 
 // ---- host-buffer wrappers (what the CLIs call) ---------------------------------

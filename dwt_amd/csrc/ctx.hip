@@ -137,11 +137,15 @@ int dwtx_encoder_part(dwtx_ctx *c, int k, dwtx_ctx **part)
 			DWTX_HIP(hipEventCreateWithFlags(&c->enc_ev[i], hipEventDisableTiming));
 		c->have_enc_ev = true;
 	}
+	if (k == 0) {   // part 0 runs on the caller's stream: the context itself, with the scratch it already has for small batches
+		*part = c;
+		return DWTX_OK;
+	}
 	if (!c->enc_part[k]) {
 		int rc = dwtx_need_side_streams(c, true);
 		if (rc)
 			return rc;
-		hipStream_t st = k == 0 ? c->stream : k == 1 ? c->aux : c->more[k - 2];
+		hipStream_t st = k == 1 ? c->aux : c->more[k - 2];
 		if ((rc = ctx_create(c->device, (void *)st, false, &c->enc_part[k])))
 			return rc;
 	}

@@ -268,6 +268,17 @@ int dwtx_decode_device(dwtx_ctx *ctx, const uint8_t *dev_streams, size_t stream_
 	const unsigned long long *dev_lens, int W, int H, int C, int n, int levels_max,
 	uint8_t *dev_pix, size_t pix_stride, dwtx_decode_info *host_info);
 
+/* The sender's side of the one exchange step between GPUs (the encoded streams of a step travel to one
+ * rank; no reference counterpart — the reference writes one file per process): the n streams of a batch, stream i at
+ * dev_streams + i*stream_stride with dev_lens[i] bytes (as dwtx_encode_device leaves them), are moved together into ONE
+ * contiguous buffer, stream i at byte offset sum over j < i of round8(dev_lens[j]) — so that a step's streams travel as one
+ * message per peer instead of one per frame.  dev_offsets (optional, [n + 1]) receives the offsets, [n] = the total; the
+ * receiver computes the same offsets from the gathered lengths.  A length beyond the stride is clamped to it; nothing is
+ * written beyond out_bytes (size it from the lengths: the sum of the rounded lengths, at most n * stream_stride).
+ * Asynchronous on the context's stream. */
+int dwtx_pack_streams(dwtx_ctx *ctx, uint8_t *dev_out, size_t out_bytes, unsigned long long *dev_offsets,
+	const uint8_t *dev_streams, size_t stream_stride, const unsigned long long *dev_lens, int n);
+
 /* Host-buffer wrappers: what encode.c:133-232 / decode.c:136-268 do between
  * read_pnm/write_pnm and the byte sink.  pixels_max < 0 = no PIXELS argument.
  * dwtx_decode_images returns DWTX_ERR_ARG for a bad header and DWTX_ERR_IO when

@@ -599,3 +599,32 @@ def test_decode_batches_in_two_three_or_four_parts(ctx, parts, opts):
     got = ctx.decode(blobs)
     for w, g in zip(want, got):
         assert (w is None and g is None) or (g is not None and g.shape == w.shape and (g == w).all())
+
+
+@pytest.mark.parametrize("n,stride", [(1, 64), (7, 4096), (200, 1024), (33, 200008)])
+def test_pack_streams_moves_a_batch_into_one_message(ctx, n, stride):
+    """dwtx_pack_streams (the sender's side of the gather between GPUs): stream i lands at the sum of the 8-byte-rounded
+    lengths before it, byte for byte; empty streams, streams that fill the stride, a length beyond the stride (clamped);
+    nothing is written past the total."""
+    import torch
+
+    from dwt_amd.dist import packed_offsets
+
+    rng = np.random.default_rng(n + stride)
+    streams = torch.from_numpy(rng.integers(0, 256, (n, stride), dtype=np.uint8)).cuda()
+    lens = rng.integers(0, stride + 1, n)
+    lens[rng.integers(0, n)] = stride
+    if n > 2:
+        lens[0] = 0
+        lens[n // 2] = stride + 100
+    off = packed_offsets(lens.tolist(), stride)
+    out = torch.full((off[-1] + 64,), 0xA5, dtype=torch.uint8, device=streams.device)
+    offs_dev = torch.zeros(n + 1, dtype=torch.int64, device=streams.device)
+    ctx.pack_streams(streams, torch.from_numpy(lens.astype(np.int64)).cuda(), out, offs_dev)
+    assert offs_dev.cpu().tolist() == off
+    o = out.cpu().numpy()
+    s = streams.cpu().numpy()
+    for i in range(n):
+        v = min(int(lens[i]), stride)
+        assert (o[off[i]:off[i] + v] == s[i, :v]).all(), i
+    assert (o[off[-1]:] == 0xA5).all()

@@ -15,13 +15,13 @@ import orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("geom,frames", [((256, 192, 3), 3), ((331, 277, 1), 2)])
-def test_two_ranks_encode_gather_decode(tmp_path, geom, frames):
+@pytest.mark.parametrize("geom,frames,mode", [((256, 192, 3), 3, "packed"), ((331, 277, 1), 2, "rows"), ((331, 277, 1), 5, "packed")])
+def test_two_ranks_encode_gather_decode(tmp_path, geom, frames, mode):
     W, H, C = geom
     dump = str(tmp_path / "gathered.npz")
     cmd = [sys.executable, os.path.join(orc.ROOT, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo",
            "--steps", "3", "--warmup", "1", "--frames", str(frames), "--geometry", str(W), str(H), str(C),
-           "--cpu-frames", "0", "--lift-reps", "1", "--dump-gathered", dump]
+           "--cpu-frames", "0", "--lift-reps", "1", "--dump-gathered", dump, "--gather", mode]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -30,7 +30,8 @@ def test_two_ranks_encode_gather_decode(tmp_path, geom, frames):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == frames
     assert line["bit_exact"]["roundtrip_lossless"] is True          # MIN over both ranks' decoded pixels == inputs
-    assert line["gathered"]["world"] == 2 and line["gathered"]["own_rows_match"] is True
+    assert line["gathered"]["world"] == 2 and line["gathered"]["own_rows_match"] is True and line["gathered"]["mode"] == mode
+    assert line["gathered"]["p2p_operations_per_step_on_rank0"] == (1 if mode == "packed" else frames)
     z = np.load(dump)
     lens = z["lens"]
     assert lens.shape == (2 * frames,)
