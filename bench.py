@@ -67,6 +67,14 @@ def git_head():
         return None
 
 
+def sources_sha16(files=("dwt_amd/csrc/pack.hip", "dwt_amd/csrc/unpack.hip")):
+    """what the kept instruction counts are stamped with (the GPU box has no .git): a hash of the entropy stage's sources"""
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def valu_peaks():
     """(full-class, fast-class) peak from the kept measurement, the constants above when the file is not there"""
     path = os.path.join(ROOT, "profiles", VALU_PEAK_FILE)
@@ -247,18 +255,12 @@ def coder_record(ctx, torch, dwt_amd, lin, W, H, C, B, stride, dev, reps=2):
             rec[name]["valu_insts_per_coefficient"] = round(per_coef * 64, 1)   # vector operations per coefficient (64 lanes per wave instruction)
             rec[name]["frac_of_valu_full_class_peak"] = round(rate / full_peak, 4)
             rec[name]["frac_of_valu_fast_class_peak"] = round(rate / fast_peak, 4)
-        stamp = ij.get("git_head")
-        stale = None
-        if stamp:
-            try:
-                diff = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", stamp, "--", "dwt_amd/csrc/pack.hip", "dwt_amd/csrc/unpack.hip"],
-                                      capture_output=True, timeout=20)
-                stale = diff.returncode != 0
-            except Exception:
-                stale = None
+        stamp = ij.get("sources_sha16")   # the counts are stamped with a hash of the kernels' sources (tools/pmc_coder.sh)
+        stale = (stamp != sources_sha16()) if stamp else None
         rec["instruction_roofline"] = {"peak_full_class_wave_insts_per_s": full_peak, "peak_fast_class_wave_insts_per_s": fast_peak,
                                        "peak_source": peak_src, "counts_source": "profiles/" + os.path.basename(ipath),
-                                       "counts_git_head": stamp, "counts_stale": stale if stamp else "unknown (no commit stamp in the file)",
+                                       "counts_sources_sha16": stamp, "sources_sha16_now": sources_sha16(),
+                                       "counts_stale": stale if stamp else "unknown (no source stamp in the file)",
                                        "note": "full class = shifts left, bit-field, permute, three-operand, packed 16-bit, DPP, select, lane reads "
                                                "(4.1 cycles per wave64 instruction per SIMD); fast class = add / sub / logic / shift right (2.4 cycles); "
                                                "the stage's kernels are mostly full class",

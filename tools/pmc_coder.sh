@@ -7,10 +7,11 @@ export DWTX_ONE_STREAM=1
 F=${1:-16}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_coder
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_coder -- python3 $GRAFT_REPO_ROOT/tools/coder_only.py 4096 4096 1 $F 2 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_coder -- python3 $GRAFT_REPO_ROOT/tools/coder_only.py 4096 4096 1 $F 2 > $GRAFT_REPO_ROOT/gpurun_out/pmc_coder.log 2>&1 || { echo "rocprofv3 failed:" >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc_coder.log >&2; exit 1; }
 cd $GRAFT_REPO_ROOT && python3 - "$F" <<'PY'
-import csv, glob, collections, json, sys
+import csv, glob, collections, hashlib, json, sys
 frames, reps = int(sys.argv[1]), 2
+stamp = hashlib.sha256(open("dwt_amd/csrc/pack.hip", "rb").read() + open("dwt_amd/csrc/unpack.hip", "rb").read()).hexdigest()[:16]
 ENC = ("k_hist", "k_plan", "k_entries", "k_cut", "k_stage_zero", "k_code", "k_carry", "k_gorder", "k_lut", "k_chain", "k_bitscan", "k_clear_stream", "k_emit", "k_refcopy", "k_order_emit")
 DEC = ("k_nch", "k_peek", "k_clear_bitmaps", "k_tiles_init", "k_spec", "k_link", "k_scan", "k_tokenize", "k_hopbits", "k_rank", "k_count", "k_apply_all", "k_seg", "k_part_reset")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -24,7 +25,7 @@ for f in glob.glob("gpurun_out/pmc_coder/**/*counter_collection.csv", recursive=
 coefs = frames * 4096 * 4096
 out = {"what": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES over tools/coder_only.py 4096 4096 1 {frames} {reps} "
                "(dwtx_encode_planes / dwtx_decode_planes on linearised coefficients; decoder on one stream)",
-       "frames": frames, "per_kernel": {}}
+       "frames": frames, "sources_sha16": stamp, "per_kernel": {}}
 for side, names in (("encode", ENC), ("decode", DEC)):
     valu = salu = 0.0
     for n, c in tot.items():

@@ -7,10 +7,10 @@
 # forward kernels load 16 B per lane, inverse kernels 8 B per lane.
 P=${1:-64}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/time_lift.py 4096 $P > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/time_lift.py 4096 $P > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_f -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_w -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > /dev/null 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/time_lift.py 4096 $P > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log >&2; exit 1; }
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_write; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/time_lift.py 4096 $P > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log >&2; exit 1; }
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_f; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_f -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_f.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_f.log >&2; exit 1; }
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_w; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_w -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_w.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc_cal_w.log >&2; exit 1; }
 cd $GRAFT_REPO_ROOT && python3 - $P <<'PY'
 import csv, glob, json, sys, collections
 P = int(sys.argv[1])

@@ -6,8 +6,8 @@
 export DWTX_ONE_STREAM=1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-	rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c -- python3 $GRAFT_REPO_ROOT/tools/time_codec.py 4096 4096 1 16 > /dev/null 2>&1
-	rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > /dev/null 2>&1
+	rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c; rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c -- python3 $GRAFT_REPO_ROOT/tools/time_codec.py 4096 4096 1 16 > $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc8_$c.log >&2; exit 1; }
+	rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c; rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c -- $GRAFT_REPO_ROOT/tools/mb/mb_copy > $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c.log 2>&1 || { echo 'rocprofv3 failed:' >&2; tail -20 $GRAFT_REPO_ROOT/gpurun_out/pmc8cal_$c.log >&2; exit 1; }
 done
 cd $GRAFT_REPO_ROOT && python3 - <<'PY'
 import csv, glob, json, collections
