@@ -69,7 +69,7 @@ class Stats(C.Structure):
 # enum dwtx_option (include/dwtx.h): diagnostic switches of a context
 OPTIONS = {name: i for i, name in enumerate((
     "exact_orders", "no_square_tiles", "part_images", "one_stream", "decode_parts", "two_families", "no_second_walk",
-    "no_index", "no_index_fallback", "no_capacity_cut", "no_fine16"))}
+    "no_index", "no_index_fallback", "no_capacity_cut", "no_fine16", "no_fused_levels"))}
 
 # name -> (restype, argtypes); must list every symbol include/dwtx.h declares
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t

@@ -710,6 +710,185 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 	store_batch(jfirst + (j1 - 1 - jfirst) / S * S);   // the last batch (a strip has at least one row pair)
 }
 
+// ---- two levels per pass (forward, int32 planes) ----
+// One launch per level moves every LL band twice more than the transform needs: written by level k, read by level k+1
+// (16 B x sum 4^-k = 21.33 B per sample forward + inverse against 16 algorithmic).  Here a wave runs level k as above and
+// hands each LL row — the lane's two LL samples are exactly one column PAIR of level k+1 — straight to a second lifting
+// stage in registers: the LL band of level k never exists in memory.  Seams: level k+1 of a lane needs the LL samples
+// of the lanes beside it, which need the input samples beside theirs; instead of halo loads the waves OVERLAP: a wave
+// loads 64 quads and owns the outputs (both levels) of lanes 2..62 — lane 1's level-k results are right without any
+// edge load (lane 0 supplies d, lane 2 its even sample), lane 2's level-k+1 results need lane 1's — 61 quads per wave,
+// 4.9 % more columns loaded; vertically a strip's first level-k+1 row pair needs the pair before it: three level-k row
+// pairs ahead of the strip and one behind it.  Shapes: w % 4 == 0 (a lane's quad) and h % 4 == 0 (both levels have
+// even heights: every row pair is whole); everything else takes one launch per level.
+struct Level2Args {
+	const int *src;  long src_ps;  int spitch;   // level k input, w x h
+	int *ll2;        long ll2_ps;  int ll2pitch; // LL of level k+1, w/4 x h/4
+	int *det;        long det_ps;  int dpitch;   // the pyramid: detail bands of both levels (Mallat layout)
+	int w, h, nquads;
+	int mpw;          // level k+1 row pairs per wave strip
+	int dbg;
+};
+constexpr int F2_FIRST = 8, F2_OWN = 48, F2_ACTIVE = F2_FIRST + F2_OWN + 1;   // lanes F2_FIRST .. F2_FIRST + F2_OWN - 1 own a wave's outputs; lanes from F2_ACTIVE on only repeat the last active lane's loads
+
+// cdf53.h:9-34 along the row for a lane's quad, neighbours by shuffle only (lanes 0 and 63 get wrong values where they
+// would need a lane that is not there: lo.a of lane 0, lo.b / hi.b of lane 63 — never used, see above)
+__device__ __forceinline__ void fwd_lift_q(const int4 &x, int q, int nquads, I2 &lo, I2 &hi)
+{
+	int xr = __shfl_down(x.x, 1);
+	if (q + 1 >= nquads)
+		xr = x.z;                         // x[w] := x[w-2]
+	const int d0 = x.y - tdiv2(x.x + x.z);
+	const int d1 = x.w - tdiv2(x.z + xr);
+	int dl = __shfl_up(d1, 1);
+	if (q <= 0)
+		dl = d0;                          // d[-1] := d[0]
+	lo.a = x.x + tdiv4(dl + d0);
+	lo.b = x.z + tdiv4(d0 + d1);
+	hi.a = d0;
+	hi.b = d1;
+}
+
+// the same one level down: the lane's LL pair (x0, x1) of a row -> (low, high)
+__device__ __forceinline__ void fwd_lift_pair(int x0, int x1, int q, int nquads, int &lo, int &hi)
+{
+	int xr = __shfl_down(x0, 1);
+	if (q + 1 >= nquads)
+		xr = x0;
+	const int d = x1 - tdiv2(x0 + xr);
+	int dl = __shfl_up(d, 1);
+	if (q <= 0)
+		dl = d;
+	lo = x0 + tdiv4(dl + d);
+	hi = d;
+}
+
+__device__ __forceinline__ int4 hold(const int4 &v) { return make_int4(hold(v.x), hold(v.y), hold(v.z), hold(v.w)); }
+
+__global__ __launch_bounds__(64 * WAVES) void k_fwd2_level_w(Level2Args a)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int strip = bx * WAVES + wv;                      // the block's waves side by side
+	if (strip * F2_OWN >= a.nquads)
+		return;
+	const int q = strip * F2_OWN - F2_FIRST + lane;         // the lane's quad of level k = its column pair of level k+1
+	const int h2 = a.h >> 1, h4 = a.h >> 2, w2 = a.w >> 1, w4 = a.w >> 2;
+	const int m0 = by * a.mpw;
+	if (m0 >= h4)
+		return;
+	const int m1 = min(m0 + a.mpw, h4);
+	const int plane = blockIdx.z;
+	const bool own = lane >= F2_FIRST && lane < F2_FIRST + F2_OWN && q < a.nquads;
+	// (every lane loads, from a clamped place: the lanes beyond the right-hand halo lane repeat its quad — no line of their own)
+	const int *src = a.src + plane * a.src_ps + 4 * min(max(q - max(lane - (F2_ACTIVE - 1), 0), 0), a.nquads - 1);
+	int *ll2 = a.ll2 + plane * a.ll2_ps;
+	int *det = a.det + plane * a.det_ps;
+
+	// LL rows of level k that the strip's row pairs m0 .. m1-1 of level k+1 need: 2 m0 - 2 (for the pair before: its
+	// detail enters the first update) .. 2 m1 (the last predict; the plane's last row pair mirrors instead)
+	const int r_lo = max(2 * m0 - 2, 0), r_hi = min(2 * m1, h2 - 1);
+	const int jfirst = max(r_lo - 1, 0);        // level k: one row pair more, for its detail
+	constexpr int S = 2;
+	auto rowp = [&](int r) { return src + (long)min(r, a.h - 1) * a.spitch; };
+	I2 l0, h0, pl = { 0, 0 }, ph = { 0, 0 };
+	fwd_lift_q(*reinterpret_cast<const int4 *>(rowp(2 * jfirst)), q, a.nquads, l0, h0);
+	int4 cur[2 * S], nxt[2 * S];
+#pragma unroll
+	for (int k = 0; k < 2 * S; ++k)
+		nxt[k] = *reinterpret_cast<const int4 *>(rowp(2 * jfirst + 1 + k));
+	// what a batch leaves for the next iteration's stores
+	I2 osh[S], odl[S], odh[S];
+	int o2[4] = { 0, 0, 0, 0 }, o2m = -1;   // a finished row pair of level k+1: LL, HL, LH, HH and its index
+	auto store_batch = [&](int jb) {
+		if (!own)
+			return;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int j = jb + s;
+			if (j >= 2 * m0 && j < 2 * m1 && !(a.dbg & 2)) {
+				st2(det + (long)j * a.dpitch + w2 + 2 * q, osh[s]);
+				st2(det + (long)(h2 + j) * a.dpitch + 2 * q, odl[s]);
+				st2(det + (long)(h2 + j) * a.dpitch + w2 + 2 * q, odh[s]);
+			}
+		}
+		if (o2m >= m0 && !(a.dbg & 1)) {
+			ll2[(long)o2m * a.ll2pitch + q] = o2[0];
+			det[(long)o2m * a.dpitch + w4 + q] = o2[1];
+			det[(long)(h4 + o2m) * a.dpitch + q] = o2[2];
+			det[(long)(h4 + o2m) * a.dpitch + w4 + q] = o2[3];
+		}
+		o2m = -1;
+	};
+	// level k+1, column direction: A = the pair's even row, B = its odd row, (pd*) the details of the pair before
+	int Al = 0, Ah = 0, Bl = 0, Bh = 0, pdl = 0, pdh = 0;
+	auto finish_pair = [&](int m, int Cl, int Ch) {
+		const int dl2 = Bl - tdiv2(Al + Cl), dh2 = Bh - tdiv2(Ah + Ch);
+		o2[0] = Al + tdiv4((m ? pdl : dl2) + dl2);
+		o2[1] = Ah + tdiv4((m ? pdh : dh2) + dh2);
+		o2[2] = dl2;
+		o2[3] = dh2;
+		o2m = m;          // (the pair before the strip, m0 - 1, is only here for its details: never stored)
+		pdl = dl2;
+		pdh = dh2;
+	};
+	for (int jb = jfirst; jb <= r_hi; jb += S) {
+#pragma unroll
+		for (int k = 0; k < 2 * S; ++k)
+			cur[k] = hold(nxt[k]);   // the one wait of the iteration (see k_fwd_level_w)
+		if (jb > jfirst)
+			store_batch(jb - S);
+		if (jb + S <= r_hi) {
+#pragma unroll
+			for (int k = 0; k < 2 * S; ++k)
+				nxt[k] = *reinterpret_cast<const int4 *>(rowp(2 * (jb + S) + 1 + k));
+		}
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const int jj = jb + s;
+			if (jj > r_hi)
+				break;
+			I2 l1, h1, l2 = l0, h2v = h0;
+			fwd_lift_q(cur[2 * s], q, a.nquads, l1, h1);
+			if (2 * jj + 2 < a.h)
+				fwd_lift_q(cur[2 * s + 1], q, a.nquads, l2, h2v);
+			const I2 dl = i2_pred(l1, l0, l2);
+			const I2 dh = i2_pred(h1, h0, h2v);
+			const I2 sl = i2_upd(l0, jj ? pl : dl, dl);
+			osh[s] = i2_upd(h0, jj ? ph : dh, dh);
+			odl[s] = dl;
+			odh[s] = dh;
+			pl = dl;
+			ph = dh;
+			l0 = l2;
+			h0 = h2v;
+			if (jj >= r_lo && !(a.dbg & 4)) {   // sl is LL row jj of level k: the lane's pair of level k+1
+				int lo2, hi2;
+				fwd_lift_pair(sl.a, sl.b, q, a.nquads, lo2, hi2);
+				if (jj & 1) {
+					Bl = lo2;
+					Bh = hi2;
+				} else {
+					if (jj > r_lo)
+						finish_pair((jj >> 1) - 1, lo2, hi2);
+					Al = lo2;
+					Ah = hi2;
+				}
+			}
+		}
+	}
+	const int jlast = jfirst + (r_hi - jfirst) / S * S;
+	if (m1 == h4) {
+		// the plane's last row pair of level k+1 has no even row below it: x[N] := x[N-2] (its B row came with the last batch)
+		store_batch(jlast);
+		finish_pair(h4 - 1, Al, Ah);
+		store_batch(jlast + S);   // (beyond the strip's rows of level k: only the finished pair goes out)
+	} else {
+		store_batch(jlast);
+	}
+}
+
 // ---- the finest level from 8-bit pixels, in packed 16-bit arithmetic ----
 // Samples of magnitude <= 255 cannot leave 16 bits anywhere in one level of cdf53.h:9-34 (|d| <= 510 after the row
 // pass, <= 1020 after the column pass; every intermediate sum stays below 2^12): the lane's two column pairs ride in
@@ -1390,6 +1569,175 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w(LevelArgsW A)
 	store_batch(j0 + (j1 - 1 - j0) / S * S);
 }
 
+// ---- two levels per pass (inverse, int32 planes): the mirror image of k_fwd2_level_w ----
+// A wave undoes level k+1 for its column pairs — one pair per lane: the lane's LL sample and its three details — and
+// hands every rebuilt LL row of level k (the lane's two samples of it) straight to the level-k stage, whose other
+// inputs are that level's detail bands: the LL band of level k is neither written nor read.  Rows of the output leave
+// as whole 128-byte lines: a wave owns the quads of lanes 4..59 (56 x 16 bytes = seven lines, at a multiple of seven
+// lines), lanes 3 and 60 load their columns only for their neighbours' row steps (undoing the columns first leaves
+// every lane's high-band samples right whatever its neighbours hold; cdf53.h:36-61), the other lanes repeat those
+// lanes' loads.  Shapes as in k_fwd2_level_w: w % 4 == 0, h % 4 == 0.
+struct Inv2Args {
+	const int *ll2;  long ll2_ps;  int ll2pitch;   // LL of level k+1, w/4 x h/4
+	const int *det;  long det_ps;  int dpitch;     // the pyramid: detail bands of both levels
+	int *dst;        long dst_ps;  int opitch;     // output, w x h
+	int w, h, nquads;
+	int mpw;          // level k+1 row pairs per wave strip
+};
+constexpr int V2_FIRST = 4, V2_OWN = 56;
+
+struct Raw2 {       // one row of level k+1 at the lane's pair: LL | HL | LH | HH
+	int sl, sh, dl, dh;
+};
+struct Raw1 {       // one row pair of level k at the lane's two pairs: HL | LH | HH (its LL comes from level k+1)
+	int2 sh, dl, dh;
+};
+__device__ __forceinline__ Raw2 hold(const Raw2 &r)
+{
+	Raw2 o = { hold(r.sl), hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
+}
+__device__ __forceinline__ Raw1 hold(const Raw1 &r)
+{
+	Raw1 o = { hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
+}
+
+// cdf53.h:36-61 along a row of level k+1 for the lane's pair (low, high) -> its two samples of level k's LL row
+__device__ __forceinline__ I2 inv_row_pair(int q, int nquads, int lo, int hi)
+{
+	int hl = __shfl_up(hi, 1);
+	if (q <= 0)
+		hl = hi;
+	const int e = lo - tdiv4(hl + hi);
+	int er = __shfl_down(e, 1);
+	if (q + 1 >= nquads)
+		er = e;
+	I2 r = { e, hi + tdiv2(e + er) };
+	return r;
+}
+
+__device__ __forceinline__ I2 i2_sub4(I2 s, I2 dp, I2 d)   // cdf53.h:40-47: the even row from its low-pass sample and the details around it
+{
+	I2 r = { s.a - tdiv4(dp.a + d.a), s.b - tdiv4(dp.b + d.b) };
+	return r;
+}
+__device__ __forceinline__ I2 i2_add2(I2 d, I2 e0, I2 e1)   // cdf53.h:49-56: the odd row
+{
+	I2 r = { d.a + tdiv2(e0.a + e1.a), d.b + tdiv2(e0.b + e1.b) };
+	return r;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int bx, by;
+	xcd_strip(bx, by);
+	if (bx * V2_OWN >= a.nquads)
+		return;
+	const int q = bx * V2_OWN - V2_FIRST + lane;
+	const int h2 = a.h >> 1, h4 = a.h >> 2, w2 = a.w >> 1, w4 = a.w >> 2;
+	const int m0 = (by * WAVES + wv) * a.mpw;
+	if (m0 >= h4)
+		return;
+	const int m1 = min(m0 + a.mpw, h4);
+	const int plane = blockIdx.z;
+	const bool own = lane >= V2_FIRST && lane < V2_FIRST + V2_OWN && q < a.nquads;
+	// every lane loads: lanes 3 and 60 for their neighbours, the ones beyond them repeat those two lanes' columns
+	const int qc = min(max(q + max(V2_FIRST - 1 - lane, 0) - max(lane - (V2_FIRST + V2_OWN), 0), 0), a.nquads - 1);
+	const int *ll2 = a.ll2 + plane * a.ll2_ps + qc;
+	const int *det = a.det + plane * a.det_ps;
+	int *dst = a.dst + plane * a.dst_ps;
+	auto load2 = [&](int m) {
+		const int mm = min(max(m, 0), h4 - 1);
+		Raw2 r = { ll2[(long)mm * a.ll2pitch], det[(long)mm * a.dpitch + w4 + qc], det[(long)(h4 + mm) * a.dpitch + qc],
+			det[(long)(h4 + mm) * a.dpitch + w4 + qc] };
+		return r;
+	};
+	auto load1 = [&](int j) {
+		const int jc = min(max(j, 0), h2 - 1);
+		Raw1 r = { ld2(det + (long)jc * a.dpitch + w2 + 2 * qc), ld2(det + (long)(h2 + jc) * a.dpitch + 2 * qc),
+			ld2(det + (long)(h2 + jc) * a.dpitch + w2 + 2 * qc) };
+		return r;
+	};
+	// level k+1, column direction: the state of pair m0
+	int d2l, d2h, e2l, e2h;
+	{
+		const Raw2 before = load2(m0 - 1), first = load2(m0);
+		d2l = first.dl;
+		d2h = first.dh;
+		e2l = first.sl - tdiv4((m0 ? before.dl : d2l) + d2l);
+		e2h = first.sh - tdiv4((m0 ? before.dh : d2h) + d2h);
+	}
+	// level k: the state of row pair 2 m0 (its LL row is level k+1's even row of pair m0)
+	I2 cdl, cdh, cel, ceh;
+	{
+		const Raw1 before = load1(2 * m0 - 1), first = load1(2 * m0);
+		const I2 sl = inv_row_pair(q, a.nquads, e2l, e2h);
+		cdl = to_i2(first.dl);
+		cdh = to_i2(first.dh);
+		cel = i2_sub4(sl, m0 ? to_i2(before.dl) : cdl, cdl);
+		ceh = i2_sub4(to_i2(first.sh), m0 ? to_i2(before.dh) : cdh, cdh);
+	}
+	Raw2 n2 = load2(m0 + 1), c2;
+	Raw1 n1a = load1(2 * m0 + 1), n1b = load1(2 * m0 + 2), c1a, c1b;
+	int4 orow[4];
+	auto store_rows = [&](int m) {
+		if (!own)
+			return;
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			*reinterpret_cast<int4 *>(dst + (long)(4 * m + k) * a.opitch + 4 * q) = orow[k];
+	};
+	// one row pair of level k: state (pair jj) + the next pair's samples -> its two output rows; the state moves on
+	auto pair1 = [&](int jj, I2 nsl, const Raw1 &n, int4 &even, int4 &odd) {
+		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = cel, neh = ceh;   // the plane's last pair mirrors: x[h] := x[h-2]
+		if (jj + 1 < h2) {
+			ndl = to_i2(n.dl);
+			ndh = to_i2(n.dh);
+			nel = i2_sub4(nsl, cdl, ndl);
+			neh = i2_sub4(to_i2(n.sh), cdh, ndh);
+		}
+		const Quad4 ev = inv_row_vals(q, a.nquads, cel, ceh);
+		const Quad4 od = inv_row_vals(q, a.nquads, i2_add2(cdl, cel, nel), i2_add2(cdh, ceh, neh));
+		even = make_int4(ev.v[0], ev.v[1], ev.v[2], ev.v[3]);
+		odd = make_int4(od.v[0], od.v[1], od.v[2], od.v[3]);
+		cdl = ndl;
+		cdh = ndh;
+		cel = nel;
+		ceh = neh;
+	};
+	for (int m = m0; m < m1; ++m) {
+		c2 = hold(n2);   // the one wait of the iteration (see k_fwd_level_w)
+		c1a = hold(n1a);
+		c1b = hold(n1b);
+		if (m > m0)
+			store_rows(m - 1);
+		if (m + 1 < m1) {
+			n2 = load2(m + 2);
+			n1a = load1(2 * m + 3);
+			n1b = load1(2 * m + 4);
+		}
+		// level k+1, pair m: its odd row, and the even row of the pair after it
+		int nd2l = 0, nd2h = 0, ne2l = e2l, ne2h = e2h;
+		if (m + 1 < h4) {
+			nd2l = c2.dl;
+			nd2h = c2.dh;
+			ne2l = c2.sl - tdiv4(d2l + nd2l);
+			ne2h = c2.sh - tdiv4(d2h + nd2h);
+		}
+		const I2 ll_odd = inv_row_pair(q, a.nquads, d2l + tdiv2(e2l + ne2l), d2h + tdiv2(e2h + ne2h));   // LL row 2m+1 of level k
+		const I2 ll_next = inv_row_pair(q, a.nquads, ne2l, ne2h);                                           // LL row 2m+2
+		d2l = nd2l;
+		d2h = nd2h;
+		e2l = ne2l;
+		e2h = ne2h;
+		pair1(2 * m, ll_odd, c1a, orow[0], orow[1]);
+		pair1(2 * m + 1, ll_next, c1b, orow[2], orow[3]);
+	}
+	store_rows(m1 - 1);
+}
+
 // The finest inverse level of an RGB image: one wave carries the same columns of the three planes
 // (Y, Co, Cg) and writes interleaved 8-bit pixels — image.h:39-50 ycocg2rgb with its input clamps and
 // the output clamp of pnm.h:108 fused in.  grid.z = image; dst8 rows are 3*w bytes.
@@ -1859,6 +2207,33 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			DWTX_LAUNCH_CHECK();
 			break;
 		}
+		// two levels in one pass where the shapes allow it (k_fwd2_level_w): plain int32 planes, no histograms
+		if (!in8 && !p16.planes && !hist_on && !ctx->opt[DWTX_OPT_NO_FUSED_LEVELS] && t + 1 < tail_from && t + 2 <= T &&
+			ws[t] % 4 == 0 && hs[t] % 4 == 0 && spitch % 4 == 0 && src_ps % 4 == 0 && aligned_to(src, 16) && W % 2 == 0 && aligned_to(out, 8)) {
+			Level2Args f;
+			f.src = src;
+			f.src_ps = src_ps;
+			f.spitch = spitch;
+			ll_dest(t + 2, f.ll2, f.ll2_ps, f.ll2pitch);
+			f.det = out;
+			f.det_ps = full_ps;
+			f.dpitch = W;
+			f.w = ws[t];
+			f.h = hs[t];
+			f.nquads = ws[t] / 4;
+			const int strips = dwtx_cdiv(f.nquads, F2_OWN), h4 = hs[t] / 4;
+			f.dbg = (int)ctx->opt[DWTX_OPT_PART_IMAGES];
+			f.mpw = (f.dbg & 8) ? 64 : 32;
+			while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
+				f.mpw >>= 1;
+			hipLaunchKernelGGL(k_fwd2_level_w, dim3(dwtx_cdiv(strips, WAVES), dwtx_cdiv(h4, f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
+			DWTX_LAUNCH_CHECK();
+			src = f.ll2;
+			src_ps = f.ll2_ps;
+			spitch = f.ll2pitch;
+			t += 2;
+			continue;
+		}
 		LevelArgs a;
 		a.w = ws[t];
 		a.h = hs[t];
@@ -2008,6 +2383,28 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			return DWTX_ERR_NOMEM;
 	}
 	const long full_ps = (long)W * H;
+	// The LL band the next step reads: the pyramid's root, then the output of the step before.  Intermediate planes live in
+	// two scratch planes — tmp[1] holds up to ws[1]*hs[1] samples, tmp[0] up to ws[2]*hs[2] — and a step never writes the
+	// plane it reads: the ws[k] x hs[k] plane goes to tmp[(k + flip) & 1].  One step at a time alternates by itself; a
+	// two-level step (k_inv2_level_w) reads plane k+2 and writes plane k, same parity, so it flips the assignment for
+	// everything after it — allowed only if all later planes still fit (fuse_ok looks ahead).
+	const int *cur = in;
+	long cur_ps = full_ps;
+	int cur_pitch = W;
+	int flip = 0;
+	auto plane_of = [&](int k, int fl) -> int * { return tmp[(k + fl) & 1]; };
+	auto fits = [&](int k, int fl) { return ((k + fl) & 1) == 1 || k >= 2; };   // (tmp[0] is the small one)
+	const bool fusing = !out8 && !(p16 && p16->planes) && !ctx->opt[DWTX_OPT_NO_FUSED_LEVELS] && W % 2 == 0 && aligned_to(in, 8) && aligned_to(out, 16);
+	auto can_fuse = [&](int t) { return fusing && t >= 1 && ws[t - 1] % 4 == 0 && hs[t - 1] % 4 == 0 && (t - 1 == 0 ? W % 4 == 0 : ws[t - 1] % 4 == 0); };
+	// can steps t .. 0 be completed, the planes from here on assigned with `fl`?  (two-level steps wherever they are possible)
+	auto chain_ok = [&](auto &&self, int t, int fl) -> bool {
+		if (t < 0)
+			return true;
+		if (can_fuse(t) && (t - 1 == 0 || fits(t - 1, fl ^ 1)) && self(self, t - 2, fl ^ 1))
+			return true;
+		return (t == 0 || fits(t, fl)) && self(self, t - 1, fl);
+	};
+	auto fuse_ok = [&](int t) { return can_fuse(t) && cur != in && (t - 1 == 0 || fits(t - 1, flip ^ 1)) && chain_ok(chain_ok, t - 2, flip ^ 1); };
 	int tail_from = T;
 	for (int t = 0; t < T; ++t)
 		if (ws[t] <= TAIL_MAX && hs[t] <= TAIL_MAX) {
@@ -2025,6 +2422,9 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 		ta.dst = t == 0 ? out : tmp[t & 1];
 		ta.dst_ps = t == 0 ? full_ps : (long)ws[t] * hs[t];
 		ta.dpitch2 = t == 0 ? W : ws[t];
+		cur = ta.dst;
+		cur_ps = ta.dst_ps;
+		cur_pitch = ta.dpitch2;
 		ta.pyr = const_cast<int *>(in);
 		ta.pyr_ps = full_ps;
 		ta.ppitch = W;
@@ -2038,20 +2438,50 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 	}
 	// step t rebuilds the ws[t]*hs[t] plane; its output goes to tmp[t&1] (t odd: the big one)
 	for (int t = tail_from - 1; t >= 0; --t) {
+		// two levels in one pass (k_inv2_level_w): steps t and t-1 — plain int32 planes, shapes whose two levels have whole row pairs
+		if (fuse_ok(t)) {
+			Inv2Args f;
+			f.ll2 = cur;           // the LL band step t reads: ws[t+1] x hs[t+1]
+			f.ll2_ps = cur_ps;
+			f.ll2pitch = cur_pitch;
+			f.det = in;
+			f.det_ps = full_ps;
+			f.dpitch = W;
+			if (t - 1 == 0) {
+				f.dst = out;
+				f.dst_ps = full_ps;
+				f.opitch = W;
+			} else {
+				f.dst = plane_of(t - 1, flip ^ 1);
+				f.dst_ps = (long)ws[t - 1] * hs[t - 1];
+				f.opitch = ws[t - 1];
+			}
+			f.w = ws[t - 1];
+			f.h = hs[t - 1];
+			f.nquads = f.w / 4;
+			{
+				const int strips = dwtx_cdiv(f.nquads, V2_OWN), h4 = f.h / 4;
+				f.mpw = 32;
+				while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
+					f.mpw >>= 1;
+				hipLaunchKernelGGL(k_inv2_level_w, dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
+				DWTX_LAUNCH_CHECK();
+				cur = f.dst;
+				cur_ps = f.dst_ps;
+				cur_pitch = f.opitch;
+				flip ^= 1;
+				--t;   // (the loop's own step takes the second)
+				continue;
+			}
+		}
 		LevelArgs a;
 		a.w = ws[t];
 		a.h = hs[t];
 		a.w2 = ws[t + 1];
 		a.h2 = hs[t + 1];
-		if (t == T - 1) {   // only without a tail: the root LL sits in the pyramid itself
-			a.src = in;
-			a.src_ps = full_ps;
-			a.spitch = W;
-		} else {
-			a.src = tmp[(t + 1) & 1];
-			a.src_ps = (long)a.w2 * a.h2;
-			a.spitch = a.w2;
-		}
+		a.src = cur;   // (without a tail the first step reads the root LL in the pyramid itself)
+		a.src_ps = cur_ps;
+		a.spitch = cur_pitch;
 		const bool bytes_out = out8 && t == 0;
 		a.src8 = nullptr;
 		a.dst8 = nullptr;
@@ -2065,7 +2495,11 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			a.ll_ps = full_ps;
 			a.llpitch = W;
 		} else {
-			a.ll = tmp[t & 1];
+			a.ll = plane_of(t, flip);
+			if (!fits(t, flip) || a.ll == cur) {   // (fuse_ok's look-ahead keeps this from happening)
+				dwtx_set_error("inverse transform: no scratch plane for step %d", t);
+				return DWTX_ERR_ARG;
+			}
 			a.ll_ps = (long)a.w * a.h;
 			a.llpitch = a.w;
 		}
@@ -2114,6 +2548,9 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			hipLaunchKernelGGL(k_inv_level, grid, dim3(64 * WAVES), 0, ctx->stream, a);
 		}
 		DWTX_LAUNCH_CHECK();
+		cur = a.ll;   // (null after the last step, which may have written 8-bit pixels: nothing reads it)
+		cur_ps = a.ll_ps;
+		cur_pitch = a.llpitch;
 	}
 	return DWTX_OK;
 }

@@ -165,6 +165,7 @@ enum dwtx_option {
 	DWTX_OPT_NO_INDEX_FALLBACK,    /* decoder: an index that is turned down is an error instead of the serial walk */
 	DWTX_OPT_NO_CAPACITY_CUT,      /* encoder: CAPACITY only clips the finished stream (all segments are coded) */
 	DWTX_OPT_NO_FINE16,            /* the finest ring stays in the int32 pyramid (no 16-bit planes for it) */
+	DWTX_OPT_NO_FUSED_LEVELS,      /* transforms on int32 planes: one launch per level (no two-levels-per-pass kernels) */
 	DWTX_OPT_COUNT
 };
 int dwtx_ctx_set_option(dwtx_ctx *ctx, int option, long value);

@@ -142,3 +142,30 @@ def test_pixel_transforms_refuse_shapes_their_kernels_do_not_take(ctx):
         t = torch.zeros((1, H, W, 1), dtype=torch.uint8, device=ctx.device)
         with pytest.raises(RuntimeError):
             ctx.transformation_fwd_pixels(t)
+
+
+@pytest.mark.parametrize("shape", [(68, 244), (132, 248), (260, 488), (516, 492), (72, 976), (128, 980), (388, 1220), (1080, 1920), (2048, 2048),
+                                   (68, 68), (512, 4), (260, 8), (1028, 260), (68, 192), (132, 196), (260, 224), (516, 228), (1040, 448), (76, 452),
+                                   (4096, 96), (644, 3588)])
+def test_two_levels_per_pass_equal_one_launch_per_level(ctx, shape, opts):
+    """k_fwd2_level_w / k_inv2_level_w (two levels of cdf53.h:9-61 / encode.c:16-30, decode.c:16-30 in one pass, the LL band between them never in memory):
+    widths around whole numbers of 61-quad wave strips, heights that end strips inside / at the end of a row pair of the
+    coarser level, the smallest shapes it takes — against the oracle, and the same bytes as one launch per level."""
+    import torch
+
+    H, W = shape
+    rng = np.random.default_rng(H + 3 * W)
+    a = rng.integers(-40000, 40000, size=(3, H, W), dtype=np.int32)
+    want = np.stack([orc.forward(a[p][:, :, None])[:, :, 0] for p in range(3)])
+    t = torch.from_numpy(a).cuda()
+    fused = ctx.transformation_fwd(t)
+    assert (fused.cpu().numpy() == want).all()
+    assert torch.equal(ctx.transformation_inv(fused), t)                       # k_inv2_level_w
+    inv_want = np.stack([orc.inverse(a[p][:, :, None])[:, :, 0] for p in range(3)])   # ... and of an arbitrary pyramid
+    inv_fused = ctx.transformation_inv(t)
+    assert (inv_fused.cpu().numpy() == inv_want).all()
+    opts.set("no_fused_levels", 1)
+    plain = ctx.transformation_fwd(t)
+    assert torch.equal(plain, fused)
+    assert torch.equal(ctx.transformation_inv(fused), t)
+    assert torch.equal(ctx.transformation_inv(t), inv_fused)

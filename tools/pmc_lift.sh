@@ -30,17 +30,17 @@ for d, c in (("pmc_cal_f", "FETCH_SIZE"), ("pmc_cal_w", "WRITE_SIZE")):
             cal[(c, n)] = (1 << 20) / (sum(v) / len(v))      # true KB / reported KB
 ff = {16: cal[("FETCH_SIZE", "copy16")], 8: cal[("FETCH_SIZE", "copy8")], 4: cal[("FETCH_SIZE", "copy4")]}
 wf = {16: cal[("WRITE_SIZE", "copy16")], 8: cal[("WRITE_SIZE", "copy8")], 4: cal[("WRITE_SIZE", "copy4")]}
-load_width = lambda n: 16 if n.startswith("k_fwd_level_w") else 8 if n.startswith("k_inv_level_w") else 4
-store_width = lambda n: 8 if n.startswith("k_fwd_level_w") else 16 if n.startswith("k_inv_level_w") else 4
+load_width = lambda n: 16 if n.startswith(("k_fwd_level_w", "k_fwd2_level_w")) else 8 if n.startswith(("k_inv_level_w", "k_inv2_level_w")) else 4
+store_width = lambda n: 8 if n.startswith(("k_fwd_level_w", "k_fwd2_level_w")) else 16 if n.startswith(("k_inv_level_w", "k_inv2_level_w")) else 4
 per = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
 pairs = 0
 for n, v in rows("pmc_fetch", "FETCH_SIZE"):
-    if "k_fwd_" in n or "k_inv_" in n:
+    if "k_fwd" in n or "k_inv" in n:
         per[n]["fetch_kb"] += v
         per[n]["launches"] += 1
         pairs += n.startswith("k_fwd_tail")
 for n, v in rows("pmc_write", "WRITE_SIZE"):
-    if "k_fwd_" in n or "k_inv_" in n:
+    if "k_fwd" in n or "k_inv" in n:
         per[n]["write_kb"] += v
 samples = P * 4096 * 4096
 out_k = {}
