@@ -714,21 +714,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_level_w(LevelArgsW A)
 // One launch per level moves every LL band twice more than the transform needs: written by level k, read by level k+1
 // (16 B x sum 4^-k = 21.33 B per sample forward + inverse against 16 algorithmic).  Here a wave runs level k as above and
 // hands each LL row — the lane's two LL samples are exactly one column PAIR of level k+1 — straight to a second lifting
-// stage in registers: the LL band of level k never exists in memory.  Seams: level k+1 of a lane needs the LL samples
-// of the lanes beside it, which need the input samples beside theirs; instead of halo loads the waves OVERLAP: a wave
-// loads 64 quads and owns the outputs (both levels) of lanes 2..62 — lane 1's level-k results are right without any
-// edge load (lane 0 supplies d, lane 2 its even sample), lane 2's level-k+1 results need lane 1's — 61 quads per wave,
-// 4.9 % more columns loaded; vertically a strip's first level-k+1 row pair needs the pair before it: three level-k row
-// pairs ahead of the strip and one behind it.  Shapes: w % 4 == 0 (a lane's quad) and h % 4 == 0 (both levels have
-// even heights: every row pair is whole); everything else takes one launch per level.
+// stage in registers: the LL band of level k never exists in memory.
+// Seams.  Level k+1 of a lane needs the LL samples of the lanes beside it, which need the input samples beside theirs.
+// Instead of halo loads the waves OVERLAP: lane 1's level-k results are right without any edge load (lane 0 supplies d,
+// lane 2 its even sample), lane 2's level-k+1 results need lane 1's; on the right one lane is enough.  Vertically a
+// strip's first row pair of level k+1 needs the pair before it: three row pairs of level k ahead of the strip, one behind.
+// What decides the kernel's speed is how its STORES meet the 128-byte lines (round 4's ablation, 64 planes of 4096x4096:
+// a pass that only reads takes 13 us per plane, the level-k detail stores add 12-16, level k+1's 4-byte stores 4-7 —
+// reads and writes do not overlap, a written byte costs 1.5 read bytes, and owning 61 lanes of 64 (rows of 488 bytes
+// at multiples of 488) was 17 % SLOWER than one launch per level although it moved 14 % fewer bytes): a wave owns the
+// outputs of 48 lanes — rows of 384 bytes (level k) and 192 bytes (level k+1; the block's four waves side by side make
+// whole lines of them) at multiples of themselves; lanes 8 .. 56 take part (the lanes before them keep the loads on
+// whole lines, the lanes after them repeat lane 56's quad), and the stores bypass the L2's allocation (nontemporal: 5 %).
+// Shapes: w % 4 == 0 (a lane's quad) and h % 4 == 0 (both levels have even heights: every row pair is whole);
+// everything else takes one launch per level.
 struct Level2Args {
 	const int *src;  long src_ps;  int spitch;   // level k input, w x h
 	int *ll2;        long ll2_ps;  int ll2pitch; // LL of level k+1, w/4 x h/4
 	int *det;        long det_ps;  int dpitch;   // the pyramid: detail bands of both levels (Mallat layout)
 	int w, h, nquads;
 	int mpw;          // level k+1 row pairs per wave strip
-	int dbg;
 };
+// (strips of 8 row pairs of level k+1 — 32 input rows — measured best, against 4, 16, 32 and 64: the halo rows a strip shares with its
+// neighbours are then still in the XCD's L2 when the neighbour asks for them, and there are eight times the waves to hide latency behind)
+constexpr int F2_MPW = 8;
 constexpr int F2_FIRST = 8, F2_OWN = 48, F2_ACTIVE = F2_FIRST + F2_OWN + 1;   // lanes F2_FIRST .. F2_FIRST + F2_OWN - 1 own a wave's outputs; lanes from F2_ACTIVE on only repeat the last active lane's loads
 
 // cdf53.h:9-34 along the row for a lane's quad, neighbours by shuffle only (lanes 0 and 63 get wrong values where they
@@ -764,6 +773,12 @@ __device__ __forceinline__ void fwd_lift_pair(int x0, int x1, int q, int nquads,
 }
 
 __device__ __forceinline__ int4 hold(const int4 &v) { return make_int4(hold(v.x), hold(v.y), hold(v.z), hold(v.w)); }
+__device__ __forceinline__ void st2nt(int *p, I2 v)
+{
+	typedef int v2i __attribute__((ext_vector_type(2)));
+	v2i x = { v.a, v.b };
+	__builtin_nontemporal_store(x, reinterpret_cast<v2i *>(p));
+}
 
 __global__ __launch_bounds__(64 * WAVES) void k_fwd2_level_w(Level2Args a)
 {
@@ -807,17 +822,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd2_level_w(Level2Args a)
 #pragma unroll
 		for (int s = 0; s < S; ++s) {
 			const int j = jb + s;
-			if (j >= 2 * m0 && j < 2 * m1 && !(a.dbg & 2)) {
-				st2(det + (long)j * a.dpitch + w2 + 2 * q, osh[s]);
-				st2(det + (long)(h2 + j) * a.dpitch + 2 * q, odl[s]);
-				st2(det + (long)(h2 + j) * a.dpitch + w2 + 2 * q, odh[s]);
+			if (j >= 2 * m0 && j < 2 * m1) {
+				st2nt(det + (long)j * a.dpitch + w2 + 2 * q, osh[s]);
+				st2nt(det + (long)(h2 + j) * a.dpitch + 2 * q, odl[s]);
+				st2nt(det + (long)(h2 + j) * a.dpitch + w2 + 2 * q, odh[s]);
 			}
 		}
-		if (o2m >= m0 && !(a.dbg & 1)) {
-			ll2[(long)o2m * a.ll2pitch + q] = o2[0];
-			det[(long)o2m * a.dpitch + w4 + q] = o2[1];
-			det[(long)(h4 + o2m) * a.dpitch + q] = o2[2];
-			det[(long)(h4 + o2m) * a.dpitch + w4 + q] = o2[3];
+		if (o2m >= m0) {
+			__builtin_nontemporal_store(o2[0], ll2 + (long)o2m * a.ll2pitch + q);
+			__builtin_nontemporal_store(o2[1], det + (long)o2m * a.dpitch + w4 + q);
+			__builtin_nontemporal_store(o2[2], det + (long)(h4 + o2m) * a.dpitch + q);
+			__builtin_nontemporal_store(o2[3], det + (long)(h4 + o2m) * a.dpitch + w4 + q);
 		}
 		o2m = -1;
 	};
@@ -863,7 +878,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd2_level_w(Level2Args a)
 			ph = dh;
 			l0 = l2;
 			h0 = h2v;
-			if (jj >= r_lo && !(a.dbg & 4)) {   // sl is LL row jj of level k: the lane's pair of level k+1
+			if (jj >= r_lo) {   // sl is LL row jj of level k: the lane's pair of level k+1
 				int lo2, hi2;
 				fwd_lift_pair(sl.a, sl.b, q, a.nquads, lo2, hi2);
 				if (jj & 1) {
@@ -1686,8 +1701,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
 		if (!own)
 			return;
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-			*reinterpret_cast<int4 *>(dst + (long)(4 * m + k) * a.opitch + 4 * q) = orow[k];
+		for (int k = 0; k < 4; ++k) {
+			typedef int v4i __attribute__((ext_vector_type(4)));
+			const v4i v = { orow[k].x, orow[k].y, orow[k].z, orow[k].w };
+			__builtin_nontemporal_store(v, reinterpret_cast<v4i *>(dst + (long)(4 * m + k) * a.opitch + 4 * q));
+		}
 	};
 	// one row pair of level k: state (pair jj) + the next pair's samples -> its two output rows; the state moves on
 	auto pair1 = [&](int jj, I2 nsl, const Raw1 &n, int4 &even, int4 &odd) {
@@ -2222,8 +2240,7 @@ static int lift_fwd(dwtx_ctx *ctx, int32_t *out, const int32_t *in, const uint8_
 			f.h = hs[t];
 			f.nquads = ws[t] / 4;
 			const int strips = dwtx_cdiv(f.nquads, F2_OWN), h4 = hs[t] / 4;
-			f.dbg = (int)ctx->opt[DWTX_OPT_PART_IMAGES];
-			f.mpw = (f.dbg & 8) ? 64 : 32;
+			f.mpw = F2_MPW;
 			while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
 				f.mpw >>= 1;
 			hipLaunchKernelGGL(k_fwd2_level_w, dim3(dwtx_cdiv(strips, WAVES), dwtx_cdiv(h4, f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
@@ -2461,7 +2478,7 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			f.nquads = f.w / 4;
 			{
 				const int strips = dwtx_cdiv(f.nquads, V2_OWN), h4 = f.h / 4;
-				f.mpw = 32;
+				f.mpw = F2_MPW;
 				while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
 					f.mpw >>= 1;
 				hipLaunchKernelGGL(k_inv2_level_w, dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
