@@ -545,7 +545,7 @@ def main():
     # HBM bytes of the same kernels from rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE in separate passes),
     # collected in a separate profiling run (profiles/): the counters cannot be read from inside this process
     traffic = traffic_detail = None
-    for tname in ("r03_lift_traffic_pmc.json", "r02_lift_traffic_pmc.json", "r01_lift_traffic_pmc.json"):
+    for tname in ("r04_lift_traffic_pmc.json", "r03_lift_traffic_pmc.json", "r02_lift_traffic_pmc.json", "r01_lift_traffic_pmc.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -599,7 +599,7 @@ def main():
             "stage_ms_per_step": {"encode": round(enc_ms, 3), "decode": round(dec_ms, 3)},
             "coder": coder,
             "roofline": {
-                "kernel": "k_fwd_level_w<int32> + k_inv_level_w<int32> (+ the LDS tail): forward+inverse CDF 5/3, all levels, on int32 planes — the "
+                "kernel": "k_fwd2_level_w + k_inv2_level_w (two levels per pass; + the LDS tail): forward+inverse CDF 5/3, all levels, on int32 planes — the "
                           "stage-level transform of include/dwtx.h (dwtx_transformation_fwd / _inv), SURVEY 8d's 16 B per sample; the codec's own "
                           "u8 / int16 kernels are priced in roofline_codec",
                 "bound": "hbm",
