@@ -520,9 +520,9 @@ def main():
             "forward_us_per_frame": round(fpx * 1e3 / B, 2), "inverse_us_per_frame": round(ipx * 1e3 / B, 2),
             "rings_as_int16_mask": m16, "roundtrip": px_ok, "traffic": None,
         }
-        u8path = os.path.join(ROOT, "profiles", "r03_lift8_traffic_pmc.json")
+        u8path = os.path.join(ROOT, "profiles", "r04_lift8_traffic_pmc.json")
         if os.path.exists(u8path) and C == 1:
-            roofline_codec["finest_level_kernels_pmc"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r03_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")
+            roofline_codec["finest_level_kernels_pmc"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r04_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")
         del pyr_px, r16, out_px
         back = None
     lin = ctx.linearization(pyr)
@@ -558,9 +558,9 @@ def main():
                 if key in tj:
                     traffic_detail[key] = tj[key]
             # the finest level's u8 kernels as the codec runs them (pixels in; LL as int32, the detail bands as int16 out and back): 3.5 B per sample
-            u8path = os.path.join(ROOT, "profiles", "r03_lift8_traffic_pmc.json")
+            u8path = os.path.join(ROOT, "profiles", "r04_lift8_traffic_pmc.json")
             if os.path.exists(u8path):
-                traffic_detail["u8_finest_level_kernels"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r03_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")
+                traffic_detail["u8_finest_level_kernels"] = dict(json.load(open(u8path))["per_kernel"], source="profiles/r04_lift8_traffic_pmc.json (tools/pmc_lift8.sh)")
             break
 
     result = None
