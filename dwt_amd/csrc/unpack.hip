@@ -377,39 +377,68 @@ __device__ __forceinline__ bool token_at(unsigned long long win, int o, int &len
 // describe that token).  Returns false if some position cannot hold a token (dead path).
 // The chunk is cut into four 32-bit segments with compile-time register indices; almost every
 // token fits the 32-bit window of its segment (v_alignbit), the rare long one takes the 64-bit path.
+// Round 4: the parse kernels issued as many SCALAR instructions as vector ones (k_link_first 1 731 against 1 620 per
+// wave, profiles/r04_pmc_kernels.txt) — and the scalar unit, one instruction per cycle for the CU's four SIMDs, has
+// exactly the capacity of the vector units at 4.1 cycles per instruction (profiles/r04_valu_peak.json): the nested
+// divergent branches around every token (fits the window? can be a token at all? goes on?) cost 16 scalar
+// instructions per token.  So the token loop has ONE condition now (`off < bound`): a lane that meets a long token,
+// stops or dies sets its bound to 0, the long token is dealt with outside the loop (a uniform test per segment) and
+// the lane then re-enters it; visit(run, neg, counts) is called for every token the loop looks at and must do nothing
+// when `counts` is false (the same token comes again from the long path).
+// (the segment loop is unrolled — the registers of a segment are compile-time indices — and the compiler then reports that it did not unroll the
+// token loops inside it as well, which nobody asked for: that diagnostic is switched off for this file's kernels)
+#pragma clang diagnostic ignored "-Wpass-failed"
 template <class F>
 __device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, F &&visit)
 {
 	const unsigned d[6] = { (unsigned)c.w0, (unsigned)(c.w0 >> 32), (unsigned)c.w1, (unsigned)(c.w1 >> 32),
 		(unsigned)c.w2, (unsigned)(c.w2 >> 32) };
+	bool dead = false, stop = false;
 #pragma unroll
 	for (int seg = 0; seg < CH_BITS / 32; ++seg) {
-		while (off < 32 * (seg + 1)) {
-			const int r = off - 32 * seg;
-			const unsigned w32 = __builtin_amdgcn_alignbit(d[seg + 1], d[seg], r);
-			int len, next;
-			unsigned run, neg;
-			const int z = w32 ? __builtin_ctz(w32) : 32;
-			const int top = o + z;
-			if (z + top + 2 <= 32) {
-				len = z + top + 2;
+		for (;;) {   // (uniform: once, and once more for every lane-token that did not fit its window)
+			const int bound = 32 * (seg + 1);
+			bool fits = !(stop || dead), go = true;
+			// the token loop: no branch inside — a token that does not fit its window, or at which the visitor stops, only
+			// takes the lane out of the loop (visit's third argument says whether the token counts)
+			while (off < bound && fits && go) {
+				// (v_alignbit takes the low five bits of the count: off itself will do; the sentinel keeps the bit search
+				// inside the word and sends an empty window down the long path)
+				const unsigned w32 = __builtin_amdgcn_alignbit(d[seg + 1], d[seg], (unsigned)off);
+				const int z = __builtin_ctz(w32 | 0x80000000u);
+				const int top = o + z;
+				const int len = z + top + 2;
+				fits = len <= 32;
 				// top remainder bits after the one, plus 2^top - 2^o = (2^z - 1) << o (bit-field extract / mask instructions)
-				run = __builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o);
-				neg = __builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u);
-				next = top >= 2 ? top - 2 : 0;
-			} else {
+				const unsigned run = __builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o);
+				const unsigned neg = __builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u);
+				go = visit(run, neg, fits);
+				const bool adv = fits && go;
+				off += adv ? len : 0;
+				o = adv ? (int)__builtin_elementwise_sub_sat((unsigned)top, 2u) : o;
+			}
+			stop = stop || !go;
+			const bool slow = !fits && !stop && !dead;
+			if (!ballot64(slow))
+				break;
+			if (slow) {
+				const int r = off & 31;
 				const unsigned long long lo64 = d[seg] | ((unsigned long long)d[seg + 1] << 32);
 				const unsigned long long w64 = r ? (lo64 >> r) | ((unsigned long long)d[seg + 2] << (64 - r)) : lo64;
-				if (!token_at(w64, o, len, run, neg, next))
-					return false;
+				int len, next;
+				unsigned run, neg;
+				if (!token_at(w64, o, len, run, neg, next)) {
+					dead = true;
+				} else if (visit(run, neg, true)) {
+					off += len;
+					o = next;
+				} else {
+					stop = true;
+				}
 			}
-			if (!visit(run, neg))
-				return true;
-			off += len;
-			o = next;
 		}
 	}
-	return true;
+	return !dead;
 }
 
 // The walker's own parse of the rest of one chunk: counts tokens and symbols from (off, o) until the
@@ -527,9 +556,9 @@ __device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *
 	if (in != 0xffff) {
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
 		int off = in & 0xff, o = in >> 8;
-		const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
-			++tok;
-			sym += (unsigned long long)run + 1ull;
+		const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
+			tok += counts ? 1u : 0u;
+			sym += counts ? (unsigned long long)run + 1ull : 0ull;
 			return true;
 		});
 		if (alive)
@@ -586,7 +615,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64))) void k_li
 		if (chunk < nch) {
 			c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
 			int off = start, o = 0;
-			const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned) { return true; });
+			const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned, bool) { return true; });
 			spec = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
 		}
 		sx[threadIdx.x] = spec;
@@ -603,9 +632,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64))) void k_li
 				unsigned short out = 0xffff;
 				if (in != 0xffff) {
 					int off = in & 0xff, o = in >> 8;
-					const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned) {
-						++tok;
-						sym += (unsigned long long)run + 1ull;
+					const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
+						tok += counts ? 1u : 0u;
+						sym += counts ? (unsigned long long)run + 1ull : 0ull;
 						return true;
 					});
 					if (alive)
@@ -919,41 +948,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 		unsigned rp = rp0;
 		bool beyond = false;   // some one fell outside the LDS window
 		const int off0 = off, o0 = o;
-		if (left == 0xffffffffu) {
-			// a stitched chunk: every token of it counts — no per-token decisions at all
-			chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
-				rp += run;
-				const unsigned wi = rp >> 4;
-				beyond = beyond || wi >= (unsigned)HB_WORDS;
-				atomicOr(&mybuf[wi < (unsigned)HB_WORDS ? wi : (unsigned)HB_WORDS], (1u | (neg << 1)) << ((rp & 15u) * 2u));
-				++rp;
-				return true;
-			});
-		} else {
-			chunk_walk(c, off, o, [&](unsigned run, unsigned neg) {
-				if (!left)
-					return false;
-				rp += run;
-				const unsigned wi = rp >> 4;
-				beyond = beyond || wi >= (unsigned)HB_WORDS;
-				atomicOr(&mybuf[wi < (unsigned)HB_WORDS ? wi : (unsigned)HB_WORDS], (1u | (neg << 1)) << ((rp & 15u) * 2u));
-				++rp;
-				--left;
-				return true;
-			});
-		}
+		// (branch-free visitors, see chunk_walk: a token that does not count ORs a zero into the row; a stitched chunk's
+		// `left` of 0xffffffff never runs out: all its tokens count)
+		chunk_walk(c, off, o, [&](unsigned run, unsigned neg, bool counts) {
+			const bool take = counts && left != 0u;
+			rp += take ? run : 0u;
+			const unsigned wi = rp >> 4;
+			beyond = beyond || (take && wi >= (unsigned)HB_WORDS);
+			atomicOr(&mybuf[wi < (unsigned)HB_WORDS ? wi : (unsigned)HB_WORDS], take ? (1u | (neg << 1)) << ((rp & 15u) * 2u) : 0u);
+			rp += take ? 1u : 0u;
+			left -= take ? 1u : 0u;
+			return left != 0u || !counts;   // (stop at the first token that is no longer this piece's)
+		});
 		if (beyond) {   // rare (long zero runs): the ones beyond the window go to memory one by one
 			unsigned rq = rp0, lq = w.hop_ntok[(long)img * w.MAX_HOPS + h];
 			int off1 = off0, o1 = o0;
-			chunk_walk(c, off1, o1, [&](unsigned run, unsigned neg) {
-				if (!lq)
-					return false;
-				rq += run;
-				if ((rq >> 4) >= (unsigned)HB_WORDS)
+			chunk_walk(c, off1, o1, [&](unsigned run, unsigned neg, bool counts) {
+				const bool take = counts && lq != 0u;
+				rq += take ? run : 0u;
+				if (take && (rq >> 4) >= (unsigned)HB_WORDS)
 					atomicOr(wp + (rq >> 4), (1u | (neg << 1)) << ((rq & 15u) * 2u));
-				++rq;
-				--lq;
-				return true;
+				rq += take ? 1u : 0u;
+				lq -= take ? 1u : 0u;
+				return lq != 0u || !counts;
 			});
 			mybuf[HB_WORDS] = 0u;
 		}
@@ -1002,15 +1019,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 			unsigned roff = (unsigned)(seg0 + w.cs[vs * n + chunk] - (base_w << 4));   // symbols from the window's first one
 			const unsigned roff0 = roff;
 			unsigned *gp = sym + base_w;
-			chunk_walk(cw, off, o, [&](unsigned run, unsigned neg) {
-				roff += run;
+			chunk_walk(cw, off, o, [&](unsigned run, unsigned neg, bool counts) {
+				roff += counts ? run : 0u;
 				const unsigned wi = roff >> 4;
-				const unsigned bits = (1u | (neg << 1)) << ((roff & 15u) * 2u);
+				const unsigned bits = counts ? (1u | (neg << 1)) << ((roff & 15u) * 2u) : 0u;
 				if (wi < (unsigned)HB_WIN)
 					atomicOr(&win[wi], bits);
-				else
+				else if (counts)
 					atomicOr(gp + wi, bits);
-				++roff;
+				roff += counts ? 1u : 0u;
 				return true;
 			});
 			if (roff > roff0) {
