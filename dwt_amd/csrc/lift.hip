@@ -1068,16 +1068,15 @@ struct RowRegs<Rgb8> {
 	typedef FwdRawRgb Used;
 };
 
-template <typename SrcT, bool HIST>
-__global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
+// CH: the YCoCg-R channel the launch's workgroup extracts, as a compile-time constant (RGB; the kernel below branches —
+// uniformly — into the three instances: Co is one subtraction per pixel pair, and neither it nor Cg needs what only Y needs;
+// with the channel as a run-time value every workgroup computed all three and selected: 1.84 -> 1.6 ms per 256 frames of 1080p)
+template <typename SrcT, bool HIST, int CH>
+__device__ __forceinline__ void fwd_pixels_body(const LevelArgsW &A, int bx, int by)
 {
 	const LevelArgs &a = A.a;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int bx, by, chan = 0;
-	if (IsRgb<SrcT>::value)
-		xcd_strip_rgb(bx, by, chan);
-	else
-		xcd_strip(bx, by);
+	const int chan = CH;
 	const int sx = (bx << A.wx_log2) + (wv & ((1 << A.wx_log2) - 1));
 	const int q = sx * 64 + lane;
 	const int j0 = (by * (WAVES >> A.wx_log2) + (wv >> A.wx_log2)) * a.rpw;
@@ -1086,8 +1085,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
 	const int j1 = min(j0 + a.rpw, a.h2);
 	const int plane = IsRgb<SrcT>::value ? (int)blockIdx.z * 3 + chan : (int)blockIdx.z;
 	const bool valid = q < A.nquads;
-	int ch;
-	const uint8_t *src = fwd_base(SrcTag<SrcT>(), a, plane, ch);
+	int ch_rt;
+	const uint8_t *src = fwd_base(SrcTag<SrcT>(), a, plane, ch_rt);
+	const int ch = CH;   // (== ch_rt)
 	int *ll = a.ll + plane * a.ll_ps;
 	short *ll16 = a.ll16 ? a.ll16 + plane * a.ll_ps : nullptr;      // (uniform)
 	int *det = a.det + plane * a.det_ps;
@@ -1211,6 +1211,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
 	}
 	// the last batch (a strip has at least one row pair)
 	store_batch(jfirst + (j1 - 1 - jfirst) / S * S);
+}
+
+template <typename SrcT, bool HIST>
+__global__ __launch_bounds__(64 * WAVES) void k_fwd_pixels_w(LevelArgsW A)
+{
+	int bx, by, chan = 0;
+	if (IsRgb<SrcT>::value) {
+		xcd_strip_rgb(bx, by, chan);
+		if (chan == 0)
+			fwd_pixels_body<SrcT, HIST, 0>(A, bx, by);
+		else if (chan == 1)
+			fwd_pixels_body<SrcT, HIST, 1>(A, bx, by);
+		else
+			fwd_pixels_body<SrcT, HIST, 2>(A, bx, by);
+	} else {
+		xcd_strip(bx, by);
+		fwd_pixels_body<SrcT, HIST, 0>(A, bx, by);
+	}
 }
 
 // ---------------------------------------------------------------- inverse ---
