@@ -628,3 +628,57 @@ def test_pack_streams_moves_a_batch_into_one_message(ctx, n, stride):
         v = min(int(lens[i]), stride)
         assert (o[off[i]:off[i] + v] == s[i, :v]).all(), i
     assert (o[off[-1]:] == 0xA5).all()
+
+
+def test_the_widest_picture_against_the_oracle(ctx):
+    """A side of exactly 32768 (DWTX_MAX_SIDE: the largest the reference's own arithmetic is defined for, DESIGN.md
+    section 7) on a picture that is not thin: 32768x2048 gray — 1024 x 1024 curve blocks on the finest level, 15 levels;
+    the stream is the oracle's byte for byte (which the thin reference-made goldens g32768x8 / c8x32768 pin on the
+    reference binary), the round trip lossless, and the other orientation likewise."""
+    import torch
+
+    for W, H in ((32768, 2048), (1024, 32768)):
+        pix = orc.synth(W, H, 1, 77, 0)
+        want, st = orc.encode(pix)
+        t = torch.from_numpy(pix[None]).cuda()
+        streams, info = ctx.encode_device(t)
+        lens = ctx.stream_lengths(info)
+        assert int(lens[0]) == len(want)
+        assert streams[0, : len(want)].cpu().numpy().tobytes() == want
+        out, infos = ctx.decode_device(streams, lens, W, H, 1)
+        assert infos[0].status == 0 and not infos[0].truncated
+        assert torch.equal(out.view(1, H, W, 1), t)
+        del t, streams, out
+        torch.cuda.empty_cache()
+
+
+def test_the_largest_picture_32768_square(ctx):
+    """32768x32768 gray, one gigapixel — the largest picture the fence of DESIGN.md section 7 lets through: lossless round
+    trip, CAPACITY gives the exact prefix of the unlimited stream, and that prefix decodes to the resolution the schedule
+    says (size-independent properties: the oracle would take minutes and 12 GB here)."""
+    import torch
+
+    W = H = 32768
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs about 120 GiB of free HBM")
+    pix = ctx.synth_pixels(1, H, W, 1, seed0=5, kind=0)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    n = int(lens[0])
+    assert 6 < n < streams.shape[1]
+    out, infos = ctx.decode_device(streams, lens, W, H, 1)
+    assert infos[0].status == 0 and not infos[0].truncated and infos[0].level == orc.geometry(W, H).levels - 1
+    assert torch.equal(out.view(1, H, W, 1), pix)
+    del out
+    cap = 3 << 20
+    cut, cinfo = ctx.encode_device(pix, capacity=cap)
+    clens = ctx.stream_lengths(cinfo)
+    assert int(clens[0]) == cap
+    assert torch.equal(cut[0, :cap], streams[0, :cap])
+    small, sinfos = ctx.decode_device(cut, clens, W, H, 1)
+    g = orc.geometry(W, H)
+    lo = sinfos[0].level + 1
+    assert sinfos[0].status == 0 and sinfos[0].truncated and 0 < lo <= g.levels
+    head = streams[0, :6].cpu().numpy().tobytes()
+    assert head == b"W5" + bytes([255, 127, 255, 127])

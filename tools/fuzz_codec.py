@@ -17,11 +17,14 @@ t0 = time.time()
 frames = 0
 for case in range(cases):
     W, H = int(rng.integers(8, 700)), int(rng.integers(8, 700))
-    kind = case % 5
+    kind = case % 6
     if kind == 0:
         W = H = int(2 ** rng.integers(3, 11))
     elif kind == 1:
         W = (W + 3) // 4 * 4
+    elif kind == 5:   # one long side, up to the largest the reference's arithmetic is defined for
+        long_side, short_side = int(rng.integers(16385, 32769)), int(rng.integers(8, 48))
+        W, H = (long_side, short_side) if rng.integers(0, 2) else (short_side, long_side)
     Cn = 1 if rng.integers(0, 2) else 3
     n = int(rng.integers(1, 7))
     def picture():
