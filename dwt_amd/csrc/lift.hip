@@ -1616,23 +1616,18 @@ struct Inv2Args {
 	int *dst;        long dst_ps;  int opitch;     // output, w x h
 	int w, h, nquads;
 	int mpw;          // level k+1 row pairs per wave strip
+	const short *det16;   // F16: the detail bands of BOTH levels as 16-bit values (positions, pitch and plane stride of det)
+	uint8_t *dst8;        // 8-bit output (the finest level of a gray picture: pnm.h:108's clamp fused), dst_ps / opitch in bytes
 };
 constexpr int V2_FIRST = 4, V2_OWN = 56;
 
 struct Raw2 {       // one row of level k+1 at the lane's pair: LL | HL | LH | HH
 	int sl, sh, dl, dh;
 };
-struct Raw1 {       // one row pair of level k at the lane's two pairs: HL | LH | HH (its LL comes from level k+1)
-	int2 sh, dl, dh;
-};
+// (one row pair of level k at the lane's two pairs — HL | LH | HH, its LL comes from level k+1 — is DetBand<F16>::raw1 below)
 __device__ __forceinline__ Raw2 hold(const Raw2 &r)
 {
 	Raw2 o = { hold(r.sl), hold(r.sh), hold(r.dl), hold(r.dh) };
-	return o;
-}
-__device__ __forceinline__ Raw1 hold(const Raw1 &r)
-{
-	Raw1 o = { hold(r.sh), hold(r.dl), hold(r.dh) };
 	return o;
 }
 
@@ -1661,16 +1656,70 @@ __device__ __forceinline__ I2 i2_add2(I2 d, I2 e0, I2 e1)   // cdf53.h:49-56: th
 	return r;
 }
 
+// the detail bands a two-level inverse step reads, and the rows it writes, as the kernel variant sees them
+template <bool F16>
+struct DetBand {
+	typedef const int *ptr;
+	struct raw1 {
+		int2 sh, dl, dh;
+	};
+	static __device__ __forceinline__ ptr of(const Inv2Args &a, long plane) { return a.det + plane * a.det_ps; }
+	static __device__ __forceinline__ int2 pair(const int *p) { return ld2(p); }
+};
+template <>
+struct DetBand<true> {
+	typedef const short *ptr;
+	struct raw1 {
+		unsigned sh, dl, dh;   // two 16-bit values each
+	};
+	static __device__ __forceinline__ ptr of(const Inv2Args &a, long plane) { return a.det16 + plane * a.det_ps; }
+	static __device__ __forceinline__ unsigned pair(const short *p) { return *reinterpret_cast<const unsigned *>(p); }
+};
+__device__ __forceinline__ DetBand<false>::raw1 hold(const DetBand<false>::raw1 &r)
+{
+	DetBand<false>::raw1 o = { hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
+}
+__device__ __forceinline__ DetBand<true>::raw1 hold(const DetBand<true>::raw1 &r)
+{
+	DetBand<true>::raw1 o = { hold(r.sh), hold(r.dl), hold(r.dh) };
+	return o;
+}
+template <typename DstT>
+struct OutPlane {
+	typedef int4 row;
+	static __device__ __forceinline__ int *of(const Inv2Args &a, long plane) { return a.dst + plane * a.dst_ps; }
+	static __device__ __forceinline__ void store(int *p, const int4 &v)
+	{
+		typedef int v4i __attribute__((ext_vector_type(4)));
+		const v4i x = { v.x, v.y, v.z, v.w };
+		__builtin_nontemporal_store(x, reinterpret_cast<v4i *>(p));
+	}
+};
+template <>
+struct OutPlane<uint8_t> {
+	typedef unsigned row;
+	static __device__ __forceinline__ uint8_t *of(const Inv2Args &a, long plane) { return a.dst8 + plane * a.dst_ps; }
+	static __device__ __forceinline__ void store(uint8_t *p, unsigned v) { __builtin_nontemporal_store(v, reinterpret_cast<unsigned *>(p)); }
+};
+
+// DstT = int: int32 rows out (nontemporal 16-byte stores; the block's four waves on top of each other).  DstT = uint8_t: the finest
+// level of a gray picture — clamped pixels, 4 bytes per lane: a wave's 224 bytes are seven 32-byte pieces, and the block's four waves
+// sit SIDE BY SIDE so that together they write seven whole lines.  F16: both levels' detail bands are 16-bit values (the codec's
+// pipelines, dwtx_p16); the arithmetic is int32 either way.
+template <typename DstT, bool F16>
 __global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
 {
+	constexpr bool SIDE = sizeof(DstT) == 1;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	int bx, by;
 	xcd_strip(bx, by);
-	if (bx * V2_OWN >= a.nquads)
+	const int strip = SIDE ? bx * WAVES + wv : bx;
+	if (strip * V2_OWN >= a.nquads)
 		return;
-	const int q = bx * V2_OWN - V2_FIRST + lane;
+	const int q = strip * V2_OWN - V2_FIRST + lane;
 	const int h2 = a.h >> 1, h4 = a.h >> 2, w2 = a.w >> 1, w4 = a.w >> 2;
-	const int m0 = (by * WAVES + wv) * a.mpw;
+	const int m0 = (SIDE ? by : by * WAVES + wv) * a.mpw;
 	if (m0 >= h4)
 		return;
 	const int m1 = min(m0 + a.mpw, h4);
@@ -1679,18 +1728,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
 	// every lane loads: lanes 3 and 60 for their neighbours, the ones beyond them repeat those two lanes' columns
 	const int qc = min(max(q + max(V2_FIRST - 1 - lane, 0) - max(lane - (V2_FIRST + V2_OWN), 0), 0), a.nquads - 1);
 	const int *ll2 = a.ll2 + plane * a.ll2_ps + qc;
-	const int *det = a.det + plane * a.det_ps;
-	int *dst = a.dst + plane * a.dst_ps;
+	const typename DetBand<F16>::ptr det = DetBand<F16>::of(a, plane);
+	DstT *dst = OutPlane<DstT>::of(a, plane);
+	typedef typename DetBand<F16>::raw1 Raw1;
 	auto load2 = [&](int m) {
 		const int mm = min(max(m, 0), h4 - 1);
-		Raw2 r = { ll2[(long)mm * a.ll2pitch], det[(long)mm * a.dpitch + w4 + qc], det[(long)(h4 + mm) * a.dpitch + qc],
-			det[(long)(h4 + mm) * a.dpitch + w4 + qc] };
+		Raw2 r = { ll2[(long)mm * a.ll2pitch], (int)det[(long)mm * a.dpitch + w4 + qc], (int)det[(long)(h4 + mm) * a.dpitch + qc],
+			(int)det[(long)(h4 + mm) * a.dpitch + w4 + qc] };
 		return r;
 	};
 	auto load1 = [&](int j) {
 		const int jc = min(max(j, 0), h2 - 1);
-		Raw1 r = { ld2(det + (long)jc * a.dpitch + w2 + 2 * qc), ld2(det + (long)(h2 + jc) * a.dpitch + 2 * qc),
-			ld2(det + (long)(h2 + jc) * a.dpitch + w2 + 2 * qc) };
+		Raw1 r = { DetBand<F16>::pair(det + (long)jc * a.dpitch + w2 + 2 * qc), DetBand<F16>::pair(det + (long)(h2 + jc) * a.dpitch + 2 * qc),
+			DetBand<F16>::pair(det + (long)(h2 + jc) * a.dpitch + w2 + 2 * qc) };
 		return r;
 	};
 	// level k+1, column direction: the state of pair m0
@@ -1714,19 +1764,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
 	}
 	Raw2 n2 = load2(m0 + 1), c2;
 	Raw1 n1a = load1(2 * m0 + 1), n1b = load1(2 * m0 + 2), c1a, c1b;
-	int4 orow[4];
+	typename OutPlane<DstT>::row orow[4];
 	auto store_rows = [&](int m) {
 		if (!own)
 			return;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			typedef int v4i __attribute__((ext_vector_type(4)));
-			const v4i v = { orow[k].x, orow[k].y, orow[k].z, orow[k].w };
-			__builtin_nontemporal_store(v, reinterpret_cast<v4i *>(dst + (long)(4 * m + k) * a.opitch + 4 * q));
-		}
+		for (int k = 0; k < 4; ++k)
+			OutPlane<DstT>::store(dst + (long)(4 * m + k) * a.opitch + 4 * q, orow[k]);
 	};
 	// one row pair of level k: state (pair jj) + the next pair's samples -> its two output rows; the state moves on
-	auto pair1 = [&](int jj, I2 nsl, const Raw1 &n, int4 &even, int4 &odd) {
+	auto pair1 = [&](int jj, I2 nsl, const Raw1 &n, typename OutPlane<DstT>::row &even, typename OutPlane<DstT>::row &odd) {
 		I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = cel, neh = ceh;   // the plane's last pair mirrors: x[h] := x[h-2]
 		if (jj + 1 < h2) {
 			ndl = to_i2(n.dl);
@@ -1736,8 +1783,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w(Inv2Args a)
 		}
 		const Quad4 ev = inv_row_vals(q, a.nquads, cel, ceh);
 		const Quad4 od = inv_row_vals(q, a.nquads, i2_add2(cdl, cel, nel), i2_add2(cdh, ceh, neh));
-		even = make_int4(ev.v[0], ev.v[1], ev.v[2], ev.v[3]);
-		odd = make_int4(od.v[0], od.v[1], od.v[2], od.v[3]);
+		even = OutRow<DstT>::of(ev);
+		odd = OutRow<DstT>::of(od);
 		cdl = ndl;
 		cdh = ndh;
 		cel = nel;
@@ -2429,17 +2476,48 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 	int flip = 0;
 	auto plane_of = [&](int k, int fl) -> int * { return tmp[(k + fl) & 1]; };
 	auto fits = [&](int k, int fl) { return ((k + fl) & 1) == 1 || k >= 2; };   // (tmp[0] is the small one)
-	const bool fusing = !out8 && !(p16 && p16->planes) && !ctx->opt[DWTX_OPT_NO_FUSED_LEVELS] && W % 2 == 0 && aligned_to(in, 8) && aligned_to(out, 16);
-	auto can_fuse = [&](int t) { return fusing && t >= 1 && ws[t - 1] % 4 == 0 && hs[t - 1] % 4 == 0 && (t - 1 == 0 ? W % 4 == 0 : ws[t - 1] % 4 == 0); };
-	// can steps t .. 0 be completed, the planes from here on assigned with `fl`?  (two-level steps wherever they are possible)
-	auto chain_ok = [&](auto &&self, int t, int fl) -> bool {
-		if (t < 0)
-			return true;
-		if (can_fuse(t) && (t - 1 == 0 || fits(t - 1, fl ^ 1)) && self(self, t - 2, fl ^ 1))
-			return true;
-		return (t == 0 || fits(t, fl)) && self(self, t - 1, fl);
+	// two levels per pass (k_inv2_level_w): int32 planes throughout, or — the codec's pipelines — both levels' detail bands as 16-bit values
+	// (dwtx_p16), the finest step then writing a gray picture's 8-bit pixels itself; an RGB picture's last step keeps its own kernel
+	const bool have16 = p16 && p16->planes;
+	const bool fusing = !ctx->opt[DWTX_OPT_NO_FUSED_LEVELS] && W % 4 == 0 && aligned_to(in, 8) && (out8 ? aligned_to(out8, 4) && out8_ps % 4 == 0 : aligned_to(out, 16)) &&
+		(!have16 || aligned_to(p16->planes, 4));
+	auto in16 = [&](int t) { return have16 && ((p16->levels >> (T - 1 - t)) & 1u) != 0; };   // step t's detail bands are 16-bit values
+	auto can_fuse = [&](int t) {
+		if (!fusing || t < 1 || ws[t - 1] % 4 != 0 || hs[t - 1] % 4 != 0 || in16(t) != in16(t - 1))
+			return false;
+		if (t - 1 == 0 && out8)
+			return out8_channels == 1 && in16(0);   // (the 8-bit variant exists for 16-bit bands only: what the pipelines run)
+		return true;
 	};
-	auto fuse_ok = [&](int t) { return can_fuse(t) && cur != in && (t - 1 == 0 || fits(t - 1, flip ^ 1)) && chain_ok(chain_ok, t - 2, flip ^ 1); };
+	// Steps t .. 0 with the planes from here on assigned with `fl`: the most samples that can go through two-level steps (a pair is
+	// worth the plane it writes: fusing the two finest levels saves sixteen times what the pair below them saves), -1 if the planes
+	// do not fit.  At most 2^16 paths, a handful in practice.
+	auto best = [&](auto &&self, int t, int fl) -> long {
+		if (t < 0)
+			return 0;
+		long b = -1;
+		if (can_fuse(t) && (t - 1 == 0 || fits(t - 1, fl ^ 1))) {
+			const long r = self(self, t - 2, fl ^ 1);
+			if (r >= 0)
+				b = r + (long)ws[t - 1] * hs[t - 1];
+		}
+		if (t == 0 || fits(t, fl)) {
+			const long r = self(self, t - 1, fl);
+			if (r > b)
+				b = r;
+		}
+		return b;
+	};
+	// take the two-level step at t if no plan that takes one step here does better
+	auto fuse_ok = [&](int t) {
+		if (!can_fuse(t) || cur == in || !(t - 1 == 0 || fits(t - 1, flip ^ 1)))
+			return false;
+		const long with = best(best, t - 2, flip ^ 1);
+		if (with < 0)
+			return false;
+		const long without = (t == 0 || fits(t, flip)) ? best(best, t - 1, flip) : -1;
+		return with + (long)ws[t - 1] * hs[t - 1] >= without;
+	};
 	int tail_from = T;
 	for (int t = 0; t < T; ++t)
 		if (ws[t] <= TAIL_MAX && hs[t] <= TAIL_MAX) {
@@ -2482,7 +2560,14 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 			f.det = in;
 			f.det_ps = full_ps;
 			f.dpitch = W;
-			if (t - 1 == 0) {
+			f.det16 = in16(t) ? p16->planes : nullptr;
+			f.dst8 = nullptr;
+			if (t - 1 == 0 && out8) {
+				f.dst = nullptr;
+				f.dst8 = out8;
+				f.dst_ps = out8_ps;
+				f.opitch = W;
+			} else if (t - 1 == 0) {
 				f.dst = out;
 				f.dst_ps = full_ps;
 				f.opitch = W;
@@ -2499,7 +2584,12 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 				f.mpw = F2_MPW;
 				while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
 					f.mpw >>= 1;
-				hipLaunchKernelGGL(k_inv2_level_w, dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
+				if (f.dst8)
+					hipLaunchKernelGGL((k_inv2_level_w<uint8_t, true>), dim3(dwtx_cdiv(strips, WAVES), dwtx_cdiv(h4, f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
+				else if (f.det16)
+					hipLaunchKernelGGL((k_inv2_level_w<int, true>), dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
+				else
+					hipLaunchKernelGGL((k_inv2_level_w<int, false>), dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
 				DWTX_LAUNCH_CHECK();
 				cur = f.dst;
 				cur_ps = f.dst_ps;

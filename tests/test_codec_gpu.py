@@ -682,3 +682,21 @@ def test_the_largest_picture_32768_square(ctx):
     assert sinfos[0].status == 0 and sinfos[0].truncated and 0 < lo <= g.levels
     head = streams[0, :6].cpu().numpy().tobytes()
     assert head == b"W5" + bytes([255, 127, 255, 127])
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024, 1), (260, 516, 1), (1080, 1920, 3), (512, 2048, 3), (68, 132, 1), (4096, 96, 1), (132, 4096, 3)])
+def test_decode_with_two_levels_per_pass_and_without(ctx, shape, opts):
+    """The decoder's transform (decode.c:258-264) fuses pairs of levels where their shapes allow it — k_inv2_level_w with the
+    detail bands as 16-bit values, the finest pair writing a gray picture's pixels itself: same pictures as one launch per
+    level, on smooth, noisy and two-level pictures (the largest steps an 8-bit source can make), whole and cut streams."""
+    H, W, Cn = shape
+    rng = np.random.default_rng(W * 3 + H)
+    pix = np.stack([orc.synth(W, H, Cn, 9, 0), orc.synth(W, H, Cn, 10, 1), (rng.integers(0, 2, (H, W, Cn)) * 255).astype(np.uint8)])
+    streams = [orc.encode(p)[0] for p in pix]
+    cuts = [s[: len(s) * 2 // 3] for s in streams]
+    for blobs in (streams, cuts):
+        want = [orc.decode(b) for b in blobs]
+        for off in (0, 1):
+            opts.set("no_fused_levels", off)
+            got = ctx.decode(blobs)
+            assert all(g.shape == w.shape and (g == w).all() for g, w in zip(got, want)), (off, blobs is cuts)
