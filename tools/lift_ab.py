@@ -13,8 +13,8 @@ def t(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3 / P
-variants = [("unfused", dict(no_fused_levels=1, part_images=0))] + [(f"fused dbg {d}", dict(no_fused_levels=0, part_images=d)) for d in (0,)]
+variants = [("one launch per level", dict(no_fused_levels=1)), ("two levels per pass", dict(no_fused_levels=0))]
 for rnd in range(2):
     for name, o in variants:
         for k, v in o.items(): ctx.set_option(k, v)
-        print(f"round {rnd} {name:14s} fwd {t(lambda: ctx.transformation_fwd(x, pyr)):6.2f} us/plane   inv {t(lambda: ctx.transformation_inv(pyr, back)):6.2f}")
+        print(f"round {rnd} {name:22s} fwd {t(lambda: ctx.transformation_fwd(x, pyr)):6.2f} us/plane   inv {t(lambda: ctx.transformation_inv(pyr, back)):6.2f}")
