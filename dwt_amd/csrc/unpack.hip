@@ -1812,6 +1812,24 @@ __global__ __launch_bounds__(256) void k_count(UnpackGeom g, DWork w, int p)
 	}
 }
 
+// Bit transpose of eight bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte p holds bit p of the eight inputs, input j at
+// bit j (the network pack.hip uses the other way round)
+__device__ __forceinline__ void bit_transpose8(unsigned &lo, unsigned &hi)
+{
+	unsigned t;
+	t = (lo ^ (lo >> 7)) & 0x00AA00AAu;
+	lo ^= t ^ (t << 7);
+	t = (hi ^ (hi >> 7)) & 0x00AA00AAu;
+	hi ^= t ^ (t << 7);
+	t = (lo ^ (lo >> 14)) & 0x0000CCCCu;
+	lo ^= t ^ (t << 14);
+	t = (hi ^ (hi >> 14)) & 0x0000CCCCu;
+	hi ^= t ^ (t << 14);
+	const unsigned nlo = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);
+	hi = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);
+	lo = nlo;
+}
+
 // Handing bits out to the coefficients of a lane, four coefficients per table look-up.
 // DEP_SYM[m][s]: m = 4-bit mask of coefficients that take a pass-1 symbol, s = the next four symbols (two bits
 // each: one flag, sign): the symbols go, in order, to the set bits of m.  Entry = ones | (signs of those ones) << 4.
@@ -1896,10 +1914,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
 	const unsigned *sym = w.symbits + img * w.BW;
 	const unsigned *stream = (const unsigned *)(streams + img * stream_stride);
 	const long stream_words = stream_stride >> 2;
-	unsigned mag[16];
+	// The planes' bits of the lane's 16 coefficients — one 16-bit row per plane, rows coming in from the highest plane down —
+	// are kept as a 256-bit shift register (eight registers: every plane pushes its row in with eight v_alignbit) and turned
+	// into magnitudes once, at the end, by two 8x8 bit transposes per eight planes.  (Until round 4 every plane set its bit in
+	// 16 magnitude registers — extract, shift, or: 48 of the ~60 vector instructions a plane costs a lane.)
+	unsigned R[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+	int p_last = 0, rows_in = 0;            // the plane of the row that came in last (halfword 0), rows so far; uniform
+	auto push_row = [&](unsigned row16) {
 #pragma unroll
-	for (int i = 0; i < 16; ++i)
-		mag[i] = 0;
+		for (int k = 7; k >= 1; --k)
+			R[k] = __builtin_amdgcn_alignbit(R[k], R[k - 1], 16);
+		R[0] = (R[0] << 16) | row16;
+		++rows_in;
+	};
 	unsigned neg = 0;                       // bit i: coefficient i of this lane is negative
 	const unsigned valid16 = nv >= 16 ? 0xffffu : (1u << nv) - 1u;
 	unsigned ins = valid16;                 // bit i: coefficient i is still insignificant
@@ -2019,11 +2046,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
 			const unsigned bits16 = ones16 | ref16;
 			neg |= sgn16;                            // the sign follows a pass-1 one (decode.c:80-85)
 			ins &= ~ones16;
-#pragma unroll
-			for (int i = 0; i < 16; ++i)
-				mag[i] |= ((bits16 >> i) & 1u) << p;
+			// (a (channel, level)'s planes come in descending order without gaps: every stream codes them that way and a cut
+			// stream loses the lowest ones; should one ever be missing, its row is all zeros)
+			for (int gap = rows_in ? p_last - p - 1 : 0; gap > 0; --gap)
+				push_row(0u);
+			push_row(bits16);
+			p_last = p;
 		}
 		sq_wave_sync();   // the next batch overwrites the slices
+	}
+	// magnitudes: halfword m of the shift register is the row of plane p_last + m; bytes of eight rows, bit-transposed, are the
+	// eight planes' bits of eight coefficients
+	unsigned mag[16];
+	{
+		unsigned lo[2], hi[2];
+#pragma unroll
+		for (int gg = 0; gg < 2; ++gg) {
+			const unsigned sel = (unsigned)gg * 0x01010101u + 0x06040200u;   // byte gg of each of four halfwords
+			lo[gg] = __builtin_amdgcn_perm(R[1], R[0], sel);
+			hi[gg] = __builtin_amdgcn_perm(R[3], R[2], sel);
+			bit_transpose8(lo[gg], hi[gg]);
+		}
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			mag[i] = __builtin_amdgcn_ubfe((i & 4) ? hi[i >> 3] : lo[i >> 3], 8u * (i & 3), 8u);
+		if (rows_in > 8) {   // uniform: more than eight planes (no 8-bit picture has them on its finest levels)
+#pragma unroll
+			for (int gg = 0; gg < 2; ++gg) {
+				const unsigned sel = (unsigned)gg * 0x01010101u + 0x06040200u;
+				lo[gg] = __builtin_amdgcn_perm(R[5], R[4], sel);
+				hi[gg] = __builtin_amdgcn_perm(R[7], R[6], sel);
+				bit_transpose8(lo[gg], hi[gg]);
+			}
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				mag[i] |= __builtin_amdgcn_ubfe((i & 4) ? hi[i >> 3] : lo[i >> 3], 8u * (i & 3), 8u) << 8;
+		}
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			mag[i] <<= p_last;
 	}
 	if (((g.sq_levels >> l) & 1u) && nvalid == TILE) {
 		// the tile is a whole 32x32 square of the pyramid: decode.c:32-65 reconstruction() for it right here,
