@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the finest-level kernels the pipelines actually run on 8-bit gray pixels (k_fwd_pixels_w<unsigned char, true> with
-# the fused histogram, k_inv_level_w<unsigned char, true>; the finest ring as 16-bit values), per sample: FETCH_SIZE / WRITE_SIZE in
+# the fused histogram, k_inv2_level_w<unsigned char, true> = the two finest levels in one pass; the finest ring as 16-bit values), per sample: FETCH_SIZE / WRITE_SIZE in
 # separate rocprofv3 passes over tools/time_codec.py 4096 4096 1 16, calibrated like tools/pmc_lift.sh on plain copies
 # (4-byte accesses: the kernels' loads and most of their stores are one word per lane).   tools/pmc_lift8.sh > profiles/rNN_lift8_traffic_pmc.json
 export DWTX_ONE_STREAM=1
@@ -24,9 +24,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for n, v in acc.items():
         if n in ("copy16", "copy8", "copy4"):
             cal[(c, n)] = (1 << 20) / (sum(v) / len(v))
-width = {"k_fwd_pixels_w<unsigned char, true>": (4, 4), "k_inv_level_w<unsigned char, true>": (4, 4)}
+width = {"k_fwd_pixels_w<unsigned char, true>": (4, 4), "k_inv2_level_w<unsigned char, true>": (4, 4)}
 out = {"what": "HBM traffic per sample of the finest-level kernels of dwtx_encode_device / dwtx_decode_device on 4096x4096 8-bit gray frames "
-               "(16 frames per call; forward: 1 B of pixels in, LL out as int16 = 0.5 B per sample, the three detail bands as int16 = 1.5 B; inverse: LL in as int32 = 1 B, details 1.5 B, pixels out 1 B)",
+               "(16 frames per call; forward: 1 B of pixels in, LL out as int16 = 0.5 B per sample, the three detail bands as int16 = 1.5 B; inverse, two levels per pass: the second level's LL in as int32 = 0.25 B per pixel, both levels' details as int16 = 1.5 + 0.375 B, pixels out 1 B)",
        "calibration_true_over_reported": {f"{c}/{n}": round(v, 3) for (c, n), v in cal.items()}, "per_kernel": {}}
 for kn, (lw, sw) in width.items():
     f = [v for n, v in rows("pmc8_FETCH_SIZE", "FETCH_SIZE") if n == kn]
@@ -35,6 +35,6 @@ for kn, (lw, sw) in width.items():
     rd = sum(f) / len(f) * cal[("FETCH_SIZE", f"copy{lw}")] * 1024 / samples
     wr = sum(wv) / len(wv) * cal[("WRITE_SIZE", f"copy{sw}")] * 1024 / samples
     out["per_kernel"][kn] = {"launches": len(f), "read_bytes_per_sample": round(rd, 3), "write_bytes_per_sample": round(wr, 3),
-                             "algorithmic_bytes_per_sample": 3.0 if kn.startswith("k_fwd") else 3.5}
+                             "algorithmic_bytes_per_sample": 3.0 if kn.startswith("k_fwd") else 3.125}
 print(json.dumps(out, indent=1))
 PY
