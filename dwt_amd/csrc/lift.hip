@@ -1918,6 +1918,144 @@ __global__ __launch_bounds__(64 * WAVES) void k_inv_level_w_rgb(LevelArgsW A)
 	store_pair(j1 - 1);
 }
 
+// The two finest levels of an RGB picture in one pass: k_inv2_level_w's two stages for the same columns of the three planes
+// (Y, Co, Cg; both levels' detail bands as 16-bit values), the colour transform and the clamps of image.h:39-50 / pnm.h:108 on
+// the finished rows, interleaved 8-bit pixels out — twelve bytes per lane: a wave's 56 owning lanes write 672 bytes = 21
+// 32-byte pieces, the block's four waves side by side 21 whole lines.  Three planes' state and rows in flight: ~150 vector
+// registers, three waves per SIMD — and still the faster way: the int32 LL planes of the second level (3 B per pixel written,
+// 3 B read) are gone.  grid.z = image.
+template <bool F16>
+__global__ __launch_bounds__(64 * WAVES) void k_inv2_level_w_rgb(Inv2Args a)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int bx, by;
+	xcd_strip(bx, by);
+	const int strip = bx * WAVES + wv;
+	if (strip * V2_OWN >= a.nquads)
+		return;
+	const int q = strip * V2_OWN - V2_FIRST + lane;
+	const int h2 = a.h >> 1, h4 = a.h >> 2, w2 = a.w >> 1, w4 = a.w >> 2;
+	const int m0 = by * a.mpw;
+	if (m0 >= h4)
+		return;
+	const int m1 = min(m0 + a.mpw, h4);
+	const int image = blockIdx.z;
+	const bool own = lane >= V2_FIRST && lane < V2_FIRST + V2_OWN && q < a.nquads;
+	const int qc = min(max(q + max(V2_FIRST - 1 - lane, 0) - max(lane - (V2_FIRST + V2_OWN), 0), 0), a.nquads - 1);
+	typedef typename DetBand<F16>::raw1 Raw1;
+	const int *ll2[3];
+	typename DetBand<F16>::ptr det[3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		ll2[ch] = a.ll2 + (long)(3 * image + ch) * a.ll2_ps + qc;
+		det[ch] = DetBand<F16>::of(a, 3 * image + ch);
+	}
+	uint8_t *dst = a.dst8 + image * a.dst_ps;
+	auto load2 = [&](int ch, int m) {
+		const int mm = min(max(m, 0), h4 - 1);
+		Raw2 r = { ll2[ch][(long)mm * a.ll2pitch], (int)det[ch][(long)mm * a.dpitch + w4 + qc], (int)det[ch][(long)(h4 + mm) * a.dpitch + qc],
+			(int)det[ch][(long)(h4 + mm) * a.dpitch + w4 + qc] };
+		return r;
+	};
+	auto load1 = [&](int ch, int j) {
+		const int jc = min(max(j, 0), h2 - 1);
+		Raw1 r = { DetBand<F16>::pair(det[ch] + (long)jc * a.dpitch + w2 + 2 * qc), DetBand<F16>::pair(det[ch] + (long)(h2 + jc) * a.dpitch + 2 * qc),
+			DetBand<F16>::pair(det[ch] + (long)(h2 + jc) * a.dpitch + w2 + 2 * qc) };
+		return r;
+	};
+	int d2l[3], d2h[3], e2l[3], e2h[3];
+	I2 cdl[3], cdh[3], cel[3], ceh[3];
+	Raw2 n2[3], c2[3];
+	Raw1 n1a[3], n1b[3], c1a[3], c1b[3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const Raw2 before2 = load2(ch, m0 - 1), first2 = load2(ch, m0);
+		d2l[ch] = first2.dl;
+		d2h[ch] = first2.dh;
+		e2l[ch] = first2.sl - tdiv4((m0 ? before2.dl : d2l[ch]) + d2l[ch]);
+		e2h[ch] = first2.sh - tdiv4((m0 ? before2.dh : d2h[ch]) + d2h[ch]);
+		const Raw1 before1 = load1(ch, 2 * m0 - 1), first1 = load1(ch, 2 * m0);
+		const I2 sl = inv_row_pair(q, a.nquads, e2l[ch], e2h[ch]);
+		cdl[ch] = to_i2(first1.dl);
+		cdh[ch] = to_i2(first1.dh);
+		cel[ch] = i2_sub4(sl, m0 ? to_i2(before1.dl) : cdl[ch], cdl[ch]);
+		ceh[ch] = i2_sub4(to_i2(first1.sh), m0 ? to_i2(before1.dh) : cdh[ch], cdh[ch]);
+		n2[ch] = load2(ch, m0 + 1);
+		n1a[ch] = load1(ch, 2 * m0 + 1);
+		n1b[ch] = load1(ch, 2 * m0 + 2);
+	}
+	Rgb12 orow[4];
+	auto store_rows = [&](int m) {
+		if (!own)
+			return;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const U32x3 v = { orow[k].w[0], orow[k].w[1], orow[k].w[2] };
+			__builtin_nontemporal_store(v, reinterpret_cast<U32x3 *>(dst + (long)(4 * m + k) * a.opitch + 12 * q));
+		}
+	};
+	for (int m = m0; m < m1; ++m) {
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			c2[ch] = hold(n2[ch]);   // the one wait of the iteration (see k_fwd_level_w)
+			c1a[ch] = hold(n1a[ch]);
+			c1b[ch] = hold(n1b[ch]);
+		}
+		if (m > m0)
+			store_rows(m - 1);
+		if (m + 1 < m1) {
+#pragma unroll
+			for (int ch = 0; ch < 3; ++ch) {
+				n2[ch] = load2(ch, m + 2);
+				n1a[ch] = load1(ch, 2 * m + 3);
+				n1b[ch] = load1(ch, 2 * m + 4);
+			}
+		}
+		Quad4 rows[3][4];
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			// level k+1, pair m: its odd row, and the even row of the pair after it
+			int nd2l = 0, nd2h = 0, ne2l = e2l[ch], ne2h = e2h[ch];
+			if (m + 1 < h4) {
+				nd2l = c2[ch].dl;
+				nd2h = c2[ch].dh;
+				ne2l = c2[ch].sl - tdiv4(d2l[ch] + nd2l);
+				ne2h = c2[ch].sh - tdiv4(d2h[ch] + nd2h);
+			}
+			const I2 ll_odd = inv_row_pair(q, a.nquads, d2l[ch] + tdiv2(e2l[ch] + ne2l), d2h[ch] + tdiv2(e2h[ch] + ne2h));
+			const I2 ll_next = inv_row_pair(q, a.nquads, ne2l, ne2h);
+			d2l[ch] = nd2l;
+			d2h[ch] = nd2h;
+			e2l[ch] = ne2l;
+			e2h[ch] = ne2h;
+			// level k, row pairs 2m and 2m+1
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				const int jj = 2 * m + half;
+				const I2 nsl = half ? ll_next : ll_odd;
+				const Raw1 &n = half ? c1b[ch] : c1a[ch];
+				I2 ndl = { 0, 0 }, ndh = { 0, 0 }, nel = cel[ch], neh = ceh[ch];   // the plane's last pair mirrors: x[h] := x[h-2]
+				if (jj + 1 < h2) {
+					ndl = to_i2(n.dl);
+					ndh = to_i2(n.dh);
+					nel = i2_sub4(nsl, cdl[ch], ndl);
+					neh = i2_sub4(to_i2(n.sh), cdh[ch], ndh);
+				}
+				rows[ch][2 * half] = inv_row_vals(q, a.nquads, cel[ch], ceh[ch]);
+				rows[ch][2 * half + 1] = inv_row_vals(q, a.nquads, i2_add2(cdl[ch], cel[ch], nel), i2_add2(cdh[ch], ceh[ch], neh));
+				cdl[ch] = ndl;
+				cdh[ch] = ndh;
+				cel[ch] = nel;
+				ceh[ch] = neh;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			orow[k] = rgb_of(rows[0][k], rows[1][k], rows[2][k]);
+	}
+	store_rows(m1 - 1);
+}
+
 // ------------------------------------------------------------ coarse tail ---
 // Once a plane is at most 64x64 all remaining levels run in one workgroup.s LDS:
 // one launch per direction replaces five to six latency-bound level launches.
@@ -2485,8 +2623,8 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 	auto can_fuse = [&](int t) {
 		if (!fusing || t < 1 || ws[t - 1] % 4 != 0 || hs[t - 1] % 4 != 0 || in16(t) != in16(t - 1))
 			return false;
-		if (t - 1 == 0 && out8)
-			return out8_channels == 1 && in16(0);   // (the 8-bit variant exists for 16-bit bands only: what the pipelines run)
+		if (t - 1 == 0 && out8)   // (the 8-bit variants exist for 16-bit bands only: what the pipelines run; RGB: three planes per wave)
+			return in16(0) && (out8_channels == 1 || (out8_channels == 3 && nplanes % 3 == 0));
 		return true;
 	};
 	// Steps t .. 0 with the planes from here on assigned with `fl`: the most samples that can go through two-level steps (a pair is
@@ -2584,7 +2722,10 @@ static int lift_inv(dwtx_ctx *ctx, int32_t *out, uint8_t *out8, long out8_ps, in
 				f.mpw = F2_MPW;
 				while (f.mpw > 2 && (long)strips * dwtx_cdiv(h4, f.mpw) * nplanes < 4096)
 					f.mpw >>= 1;
-				if (f.dst8)
+				if (f.dst8 && out8_channels == 3) {
+					f.opitch = 3 * W;
+					hipLaunchKernelGGL(k_inv2_level_w_rgb<true>, dim3(dwtx_cdiv(strips, WAVES), dwtx_cdiv(h4, f.mpw), nplanes / 3), dim3(64 * WAVES), 0, ctx->stream, f);
+				} else if (f.dst8)
 					hipLaunchKernelGGL((k_inv2_level_w<uint8_t, true>), dim3(dwtx_cdiv(strips, WAVES), dwtx_cdiv(h4, f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
 				else if (f.det16)
 					hipLaunchKernelGGL((k_inv2_level_w<int, true>), dim3(strips, dwtx_cdiv(h4, WAVES * f.mpw), nplanes), dim3(64 * WAVES), 0, ctx->stream, f);
