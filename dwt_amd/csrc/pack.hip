@@ -2464,6 +2464,30 @@ int dwtx_hist_begin(dwtx_ctx *ctx, int W, int H, int C, int n, dwtx_hist_sink *s
 	return DWTX_OK;
 }
 
+#ifdef DWTX_DEBUG_HOOKS
+// Development builds only (tools/dbg_hist.py; not in include/dwtx.h, not in the product library): the tiles' histogram records
+// as the last forward transform of this geometry left them — host_cum32 [n*C][NT][16], host_mx [n*C][NTP], tile_first [levels + 1].
+extern "C" int dwtx_debug_hist_copy(dwtx_ctx *ctx, int W, int H, int C, int n, unsigned *host_cum32, unsigned *host_mx, int *NT, int *NTP, int *tile_first)
+{
+	PackGeom g;
+	Work w;
+	dwtx_tiles tiles;
+	const int rc = pack_geometry(ctx, W, H, C, n, g, w, tiles);
+	if (rc)
+		return rc;
+	*NT = w.NT;
+	*NTP = w.NTP;
+	for (int l = 0; l <= g.levels; ++l)
+		tile_first[l] = tiles.tile_first[l];
+	if (host_cum32) {
+		DWTX_HIP(hipMemcpyAsync(host_cum32, w.cum, sizeof(unsigned) * 16 * (size_t)n * C * w.NT, hipMemcpyDeviceToHost, ctx->stream));
+		DWTX_HIP(hipMemcpyAsync(host_mx, w.tile_mx, sizeof(unsigned) * (size_t)n * C * w.NTP, hipMemcpyDeviceToHost, ctx->stream));
+		DWTX_HIP(hipStreamSynchronize(ctx->stream));
+	}
+	return DWTX_OK;
+}
+#endif
+
 // pyr / sq_levels: the ring levels flagged in sq_levels are not in `lin`; their tiles are read from the
 // 32x32 squares of the pyramid planes `pyr` (same plane order, pitch W) — see hilbert_dev.h
 int dwtx_encode_planes_ex(dwtx_ctx *ctx, const int32_t *lin, const int32_t *pyr, unsigned sq_levels, unsigned hist_levels, int W, int H, int C,
