@@ -157,6 +157,7 @@ struct DWork {
 	int *idx_nsegs;                 // [n] segments in idx (indexed walk: 0 = no usable index for this image)
 	unsigned *seg_slot;             // [n][MAX_SEGS + 1] indexed walk: first hop record of every segment's private stretch
 	int fam;                        // families in use this pass: 1 (the usual case) or FAM (see k_link_first); the tables keep FAM rows per image either way
+	unsigned streak_max, scans_base;   // the one-family walk's patience with chunks it parses by hand (k_tokenize)
 };
 
 // grid row -> virtual stream (image * FAM + family) when only w.fam of the FAM families run
@@ -1208,6 +1209,11 @@ __device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&p
 	return stop;
 }
 
+// Hand-parsed chunks in a row / in all (plus 16 per segment and 1 per 512 chunks) before the one-family walk gives up.  A chunk
+// parsed by hand costs the walk 1.7 us, the second walk of a 4096x4096 frame 1.6 ms: patience up to a few hundred chunks in a row is
+// cheaper than giving up (round 4: two of the benchmark's first 256 synthetic frames have a stretch of 49..128 such chunks and
+// took the second walk under the earlier limit of 48; tools/walk_patience.py).
+constexpr unsigned WALK_STREAK_MAX = 256u, WALK_SCANS_BASE = 256u;
 constexpr unsigned WALK_GAVE_UP = 0xffffffffu;   // DecInfo::hops of an image whose one-family walk was abandoned
 
 __device__ __forceinline__ void info_begin(DecInfo &I, const UnpackGeom &g)
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 						// parse the rest of this chunk ourselves, counting only; k_hopbits sets the bits later
 						++scans;
 						++streak;
-						if (w.fam < FAM && (streak > 48u || scans > 256u + 16u * (unsigned)nsegs + (unsigned)(lastsafe >> 9))) {
+						if (w.fam < FAM && (streak > w.streak_max || scans > w.scans_base + 16u * (unsigned)nsegs + (unsigned)(lastsafe >> 9))) {
 							giveup = true;
 							return false;
 						}
@@ -2219,6 +2225,14 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 #ifdef DWTX_DEBUG_HOOKS   // tools/dbg_walker.py: device address for the walker's cycle counters (never in the shipped build)
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 #endif
+	w.streak_max = WALK_STREAK_MAX;
+	w.scans_base = WALK_SCANS_BASE;
+#ifdef DWTX_DEBUG_HOOKS   // tools/find_second_walk.py: other limits to try
+	if (getenv("DWTX_DBG_STREAK"))
+		w.streak_max = (unsigned)strtoul(getenv("DWTX_DBG_STREAK"), 0, 0);
+	if (getenv("DWTX_DBG_SCANS"))
+		w.scans_base = (unsigned)strtoul(getenv("DWTX_DBG_SCANS"), 0, 0);
+#endif
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
 	w.BW = ((long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 128 + 3) & ~3l;   // 2 bits per symbol; whole 16-byte groups per image
 	{
@@ -2465,10 +2479,35 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 				any = any || host_info[i].hops == WALK_GAVE_UP;
 			return any;
 		};
-		auto reset_part = [&]() -> int {
-			const long items = (long)cnt * FAM * LINK_SHARDS > (long)cnt * 48 * MAX_PLANES ? (long)cnt * FAM * LINK_SHARDS : (long)cnt * 48 * MAX_PLANES;
-			hipLaunchKernelGGL(k_part_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, h, cnt);
-			DWTX_HIP(hipMemsetAsync(h.symbits, 0, sizeof(unsigned) * (size_t)cnt * w.BW, st));
+		// Only the images whose walk gave up are done again, run by run of consecutive ones (the tables are per image;
+		// the other images of the part keep what their walks found).  Round 4: one frame in 200 of the benchmark's
+		// synthetic ones takes the second walk — repeating its whole part of 48 frames cost the batch 40 % of its
+		// decoding time (18.5 -> 27.2 ms for 160 -> 192 frames), repeating the one frame is lost in it.
+		auto again = [&](int fam, bool tables) -> int {
+			int rc3 = DWTX_OK;
+			for (int i = i0; i < i0 + cnt && !rc3;) {
+				if (host_info[i].hops != WALK_GAVE_UP) {
+					++i;
+					continue;
+				}
+				int j = i + 1;
+				while (j < i0 + cnt && host_info[j].hops == WALK_GAVE_UP)
+					++j;
+				const int c = j - i;
+				const DWork hs = slice(i);
+				const long items = (long)c * FAM * LINK_SHARDS > (long)c * 48 * MAX_PLANES ? (long)c * FAM * LINK_SHARDS : (long)c * 48 * MAX_PLANES;
+				hipLaunchKernelGGL(k_part_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, hs, c);
+				DWTX_HIP(hipMemsetAsync(hs.symbits, 0, sizeof(unsigned) * (size_t)c * w.BW, st));
+				if (tables)
+					rc3 = pre(st, i, c, fam);
+				if (!rc3)
+					rc3 = walk(st, i, c, fam, false);
+				i = j;
+			}
+			if (rc3)
+				return rc3;
+			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+			DWTX_HIP(hipStreamSynchronize(st));
 			return DWTX_OK;
 		};
 		int rc2;
@@ -2477,20 +2516,16 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 				dwtx_set_error("the sidecar index does not fit the stream (DWTX_OPT_NO_INDEX_FALLBACK forbids the serial walk)");
 				return DWTX_ERR_DEVICE;
 			}
-			if ((rc2 = reset_part()) || (rc2 = walk(st, i0, cnt, fam0, false)))
+			if ((rc2 = again(fam0, false)))
 				return rc2;
-			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
-			DWTX_HIP(hipStreamSynchronize(st));
 		}
 		if (gave_up()) {
 			if (ctx->opt[DWTX_OPT_NO_SECOND_WALK]) {   // test hook: shows that a stream takes this path
 				dwtx_set_error("the one-family token walk gave up (DWTX_OPT_NO_SECOND_WALK forbids the second)");
 				return DWTX_ERR_DEVICE;
 			}
-			if ((rc2 = reset_part()) || (rc2 = pre(st, i0, cnt, FAM)) || (rc2 = walk(st, i0, cnt, FAM, false)))
+			if ((rc2 = again(FAM, true)))
 				return rc2;
-			DWTX_HIP(hipMemcpyAsync(host_info + i0, h.info, sizeof(DecInfo) * (size_t)cnt, hipMemcpyDeviceToHost, st));
-			DWTX_HIP(hipStreamSynchronize(st));
 		}
 		if (ix_out)   // the index of every stream that was decoded to its end (the serial walk wrote it, the indexed one proved it)
 			for (int i = i0; i < i0 + cnt; ++i) {

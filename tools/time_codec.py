@@ -13,6 +13,15 @@ for name in dwt_amd._lib.OPTIONS:   # the library reads no environment: DWTX_ONE
 pix = ctx.synth_pixels(n, H, W, C, 0, 0)
 streams, info = ctx.encode_device(pix)
 lens = ctx.stream_lengths(info)
+if os.environ.get("TIGHT_STRIDE"):   # rows as wide as the streams need (x1.5) instead of the worst-case bound: the decoder's tables follow the stride
+    stride = (int(lens.max().item()) * 3 // 2 + 64 + 7) // 8 * 8
+    streams = torch.empty((n, stride), dtype=torch.uint8, device=pix.device)
+    streams, info = ctx.encode_device(pix, out=streams, info=info)
+    lens = ctx.stream_lengths(info)
+    ctx.close(); ctx = dwt_amd.Context(0)   # (scratch sized for the worst-case stride goes)
+    for name in dwt_amd._lib.OPTIONS:
+        if os.environ.get("DWTX_" + name.upper()):
+            ctx.set_option(name, int(os.environ["DWTX_" + name.upper()]))
 out, infos = ctx.decode_device(streams, lens, W, H, C)
 torch.cuda.synchronize()
 assert torch.equal(out.view(n, H, W, C), pix)
