@@ -544,22 +544,34 @@ constexpr int CHUNK_GRID = 2048;
 // round.  Only the first round touches every chunk; afterwards a few percent, then a few per mille.
 // After r rounds a chunk's entry state is what a parse started r chunks earlier arrives with.
 constexpr int LINK_SHARDS = 64;   // work lists are sharded: one counter would serialise the appends in L2
+constexpr int LINK_RUN = 8;       // chunks a thread of k_link_first parses one after the other (runs start at multiples of it)
+constexpr int RUN_W = 2 * LINK_RUN + 2;   // 64-bit LDS words per thread there
+
+// Symbols of a chunk are counted in 32 bits, saturating (a run is below 2^32, vli.h:86-101; no segment asks for 2^31
+// symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over).
+__device__ __forceinline__ unsigned sym_add(unsigned sym, unsigned run, bool counts)
+{
+	return __builtin_elementwise_add_sat(sym, counts ? run + 1u : 0u);
+}
 
 // returns true if the chunk's exit moved (its successor must be re-parsed)
+// (Round 4 tried to go on with the successor in the same thread while the exit moves, up to the end of the run of
+// LINK_RUN chunks: fewer rounds for the same reach — but reach is what hurts: paths that come out of the raw refinement
+// blocks then run 8 times as far into the first-pass stretches and replace records that were right; the walker's hops
+// went from 230 to 300 per frame and its time from 13.6 to 21.5 us.)
 __device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *streams, long stream_stride, int vs, long ch)
 {
 	const int img = vs / FAM;
 	const long ci = vs * (w.NCH + 1) + ch;
 	const unsigned short in = w.exitX[vs * w.NCH + ch - 1];
-	unsigned long long sym = 0;
-	unsigned tok = 0;
+	unsigned sym = 0, tok = 0;
 	unsigned short out = 0xffff;
 	if (in != 0xffff) {
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
 		int off = in & 0xff, o = in >> 8;
 		const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
 			tok += counts ? 1u : 0u;
-			sym += counts ? (unsigned long long)run + 1ull : 0ull;
+			sym = sym_add(sym, run, counts);
 			return true;
 		});
 		if (alive)
@@ -595,61 +607,104 @@ __device__ __forceinline__ void link_push(const DWork &w, int vs, long ch, bool 
 	}
 }
 
-// Speculation and the first relaxation round in one kernel: a thread parses its chunk from the speculative start —
-// the chunk's first bit at order 0; with two families its middle plus the family's parity: at order 0 every token
-// has even length (2z + o + 2), so two parses that start an odd number of bits apart cannot meet while the order
-// stays 0 — hands the exit to its right-hand neighbour through LDS, and parses the chunk again from the exit its
-// left-hand neighbour speculated, recording counts.  A chunk whose linked exit differs from its speculated one
-// hands its successor to the work list (round 2).  The chunk's words are loaded once and no table travels through
-// memory between the two parses (rounds 1-2 used to be k_spec + k_link_all: 1.93 -> 1.77 ms per 64 frames).
-// A workgroup's first thread only speculates: its chunk is linked by the workgroup before (strides of 255 chunks).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64))) void k_link_first(DWork w, const unsigned char *streams, long stream_stride)
+// Speculation and the first relaxation round in one kernel.  Until round 4 a thread parsed ONE chunk twice: from the
+// speculative start (the chunk's first bit at order 0) and again from the exit its left-hand neighbour speculated —
+// two parses per chunk, of which the first is thrown away.  Now a thread parses a RUN of LINK_RUN chunks one after
+// the other, carrying the state along, after one chunk of warm-up (the chunk before its run, from the speculative
+// start; nothing of it is recorded): 1 + 1/LINK_RUN parses per chunk, and inside a run every record is made from
+// the state its predecessor leaves in by construction — also in the raw refinement blocks (most of a stream's bits),
+// where every parse is arbitrary and the one-chunk scheme kept the later rounds busy re-parsing records nobody uses.
+// Only a run's first chunk can be wrong (its warm-up had not met the path of the run before): it goes to the work list
+// (round 2) when the warm-up's exit is not the exit the run before recorded; a workgroup's first run always does.
+// With two families the speculative start is the chunk's middle plus the family's parity: at order 0 every token has
+// even length (2z + o + 2), so two parses that start an odd number of bits apart cannot meet while the order stays 0.
+// A path that dies (no token this codec writes fits there) starts again from the speculative start in the next chunk;
+// the record's entry then differs from its predecessor's exit, which is what flags it (k_scan_local).
+// The workgroup's stretch of the stream (32 KB) is staged in LDS with coalesced loads, a thread's run 18 words apart
+// (two words of padding: the 64 lanes' 8-byte reads spread over all banks).
+// A chunk's record as one word on its way through LDS: symbols (31 bits, saturating: a count no segment can ask for — a
+// ring has at most 2^30 coefficients — so such a chunk is simply never hopped over), tokens (7 bits: at most 64 start in
+// 128 bits), entry and exit state (13 bits each: offset 7, order 5; all ones = dead).  All ones = no record.
+__device__ __forceinline__ unsigned link_state13(unsigned short s) { return s == 0xffff ? 0x1fffu : ((unsigned)s & 0x7fu) | ((unsigned)s >> 8) << 7; }
+__device__ __forceinline__ unsigned short link_state16(unsigned s) { return s == 0x1fffu ? (unsigned short)0xffff : (unsigned short)((s & 0x7fu) | (s >> 7) << 8); }
+__device__ __forceinline__ unsigned long long link_record(unsigned sym, unsigned tok, unsigned short in, unsigned short out)
 {
+	const unsigned long long s31 = sym < 0x7fffffffu ? sym : 0x7fffffffu;
+	return s31 | (unsigned long long)tok << 31 | (unsigned long long)link_state13(in) << 38 | (unsigned long long)link_state13(out) << 51;
+}
+
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64), amdgpu_waves_per_eu(4))) void k_link_first(DWork w, const unsigned char *streams, long stream_stride)
+{
+	__shared__ unsigned long long words[256 * RUN_W + 4];
 	__shared__ unsigned short sx[256];
 	const int vs = vstream(w, blockIdx.y), img = vs / FAM;
 	const long nch = w.nch[img];
-	const int start = (w.fam == 1 ? 0 : CH_BITS / 2) + vs % FAM;
-	for (long base = (long)blockIdx.x * 255; base < nch; base += (long)gridDim.x * 255) {   // uniform
-		const long chunk = base + threadIdx.x;
-		ChunkWin c = { 0ull, 0ull, 0ull };
-		unsigned short spec = 0xffff;
-		if (chunk < nch) {
-			c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, chunk);
-			int off = start, o = 0;
-			const bool alive = chunk_walk(c, off, o, [](unsigned, unsigned, bool) { return true; });
-			spec = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
+	const unsigned short start = (unsigned short)((w.fam == 1 ? 0 : CH_BITS / 2) + vs % FAM);
+	const unsigned long long *w64 = (const unsigned long long *)(streams + img * stream_stride);
+	const long n64 = stream_stride >> 3;
+	constexpr long SPAN = 256 * LINK_RUN;   // chunks per workgroup and stride
+	for (long base = (long)blockIdx.x * SPAN; base < nch; base += (long)gridDim.x * SPAN) {   // uniform
+		// words [2 (base - 1), 2 (base + SPAN) + 1) of the stream: the chunk before the stretch, the stretch, one word of look-ahead
+		const long g0 = 2 * (base - 1);
+#pragma unroll
+		for (int k = 0; k < (2 * (int)SPAN + 3 + 255) / 256; ++k) {
+			const int L = k * 256 + (int)threadIdx.x;
+			const long gi = g0 + L;
+			if (L < 2 * (int)SPAN + 3)
+				words[L + (L / (2 * LINK_RUN)) * 2] = gi >= 0 && gi < n64 ? w64[gi] : 0ull;
 		}
-		sx[threadIdx.x] = spec;
 		__syncthreads();
-		bool moved = false;
-		if (chunk < nch) {
-			if (chunk == 0) {
-				w.exitX[vs * w.NCH] = spec;
-			} else if (threadIdx.x) {
-				const unsigned short in = sx[threadIdx.x - 1];
-				const long ci = vs * (w.NCH + 1) + chunk;
-				unsigned long long sym = 0;
-				unsigned tok = 0;
-				unsigned short out = 0xffff;
-				if (in != 0xffff) {
-					int off = in & 0xff, o = in >> 8;
-					const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
-						tok += counts ? 1u : 0u;
-						sym += counts ? (unsigned long long)run + 1ull : 0ull;
-						return true;
-					});
-					if (alive)
-						out = (unsigned short)((off - CH_BITS) | (o << 8));
+		const long c0 = base + (long)threadIdx.x * LINK_RUN;
+		unsigned long long *mine = words + threadIdx.x * RUN_W;
+		auto word = [&](int i) { return mine[i + (i >= 2 * LINK_RUN ? 2 : 0)]; };   // (words 2 LINK_RUN.. are the next thread's first)
+		unsigned short st = start, wexit = 0xffff;
+		unsigned long long carry = word(0);
+		for (int j = 0; j <= LINK_RUN; ++j) {   // j = 0: the warm-up chunk
+			const long chunk = c0 - 1 + j;
+			ChunkWin c = { carry, word(2 * j + 1), word(2 * j + 2) };
+			carry = c.w2;
+			unsigned long long rec = ~0ull;
+			if (chunk >= 0 && chunk < nch) {
+				const unsigned short in = j == 0 || chunk == 0 || st == 0xffff ? start : st;
+				int off = in & 0xff, o = in >> 8;
+				unsigned sym = 0, tok = 0;
+				const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
+					tok += counts ? 1u : 0u;
+					sym = sym_add(sym, run, counts);
+					return true;
+				});
+				st = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
+				rec = link_record(sym, tok, in, st);
+			}
+			// The records leave through LDS (one word each, over stream words this thread has consumed and no other thread
+			// reads: 3 .. LINK_RUN + 2 of its stretch), so that they go to memory side by side: written from here, a wave's
+			// store would touch 64 cache lines, LINK_RUN times over.
+			if (j == 0)
+				wexit = st;
+			else
+				mine[2 + j] = rec;
+		}
+		sx[threadIdx.x] = st;
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < LINK_RUN; ++k) {
+			const int q = k * 256 + (int)threadIdx.x;
+			const long chunk = base + q;
+			const unsigned long long rec = words[(q / LINK_RUN) * RUN_W + 3 + q % LINK_RUN];
+			if (rec != ~0ull) {   // (a chunk past the stream's end has none)
+				if (chunk > 0) {
+					w.entryE[vs * w.NCH + chunk] = link_state16((unsigned)(rec >> 38) & 0x1fffu);
+					w.cs[vs * (w.NCH + 1) + chunk] = rec & 0x7fffffffull;
+					w.ct[vs * (w.NCH + 1) + chunk] = (unsigned)(rec >> 31) & 0x7fu;
 				}
-				w.entryE[vs * w.NCH + chunk] = in;
-				w.cs[ci] = sym;
-				w.ct[ci] = tok;
-				w.exitX[vs * w.NCH + chunk] = out;
-				moved = out != spec && chunk + 1 < nch;   // the successor was linked from `spec`
+				w.exitX[vs * w.NCH + chunk] = link_state16((unsigned)(rec >> 51));
 			}
 		}
-		link_push(w, vs, chunk + 1, moved && threadIdx.x != 0, w.todo[1], w.todo_count + 2 * w.todo_round);
-		__syncthreads();   // sx is reused by the next stride
+		// the run's first chunk was parsed from the warm-up's exit: right only if that is what the run before recorded as its last exit
+		const bool redo = c0 > 0 && c0 < nch && (threadIdx.x == 0 || sx[threadIdx.x - 1] != wexit);
+		link_push(w, vs, c0, redo, w.todo[1], w.todo_count + 2 * w.todo_round);
+		__syncthreads();   // words and sx are reused by the next stride
 	}
 }
 
@@ -2225,6 +2280,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 #ifdef DWTX_DEBUG_HOOKS   // tools/dbg_walker.py: device address for the walker's cycle counters (never in the shipped build)
 	w.dbg = (unsigned long long *)getenv("DWTX_DBG_PTR") ? (unsigned long long *)strtoull(getenv("DWTX_DBG_PTR"), 0, 0) : nullptr;
 #endif
+	int link_rounds = LINK_ROUNDS;
 	w.streak_max = WALK_STREAK_MAX;
 	w.scans_base = WALK_SCANS_BASE;
 #ifdef DWTX_DEBUG_HOOKS   // tools/find_second_walk.py: other limits to try
@@ -2232,6 +2288,8 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		w.streak_max = (unsigned)strtoul(getenv("DWTX_DBG_STREAK"), 0, 0);
 	if (getenv("DWTX_DBG_SCANS"))
 		w.scans_base = (unsigned)strtoul(getenv("DWTX_DBG_SCANS"), 0, 0);
+	if (getenv("DWTX_DBG_ROUNDS") && atoi(getenv("DWTX_DBG_ROUNDS")) >= 1 && atoi(getenv("DWTX_DBG_ROUNDS")) <= LINK_ROUNDS)
+		link_rounds = atoi(getenv("DWTX_DBG_ROUNDS"));
 #endif
 	// every segment owns ceil32(ring size) symbol slots; at most MAX_PLANES segments per (channel, level)
 	w.BW = ((long)((((unsigned long long)g.total + 32ull * g.levels) * C * MAX_PLANES) >> 4) + 128 + 3) & ~3l;   // 2 bits per symbol; whole 16-byte groups per image
@@ -2401,11 +2459,11 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		const unsigned char *str = streams + (size_t)i0 * stream_stride;
 		const unsigned cblocks = (unsigned)((w.NCH + 1 + 255) / 256);
 		const dim3 cg(cblocks < CHUNK_GRID ? cblocks : CHUNK_GRID, cnt * h.fam);
-		const unsigned fblocks = (unsigned)((w.NCH + 1 + 254) / 255);
+		const unsigned fblocks = (unsigned)((w.NCH + 1 + 256 * LINK_RUN - 1) / (256 * LINK_RUN));
 		hipLaunchKernelGGL(k_link_first, dim3(fblocks < CHUNK_GRID ? fblocks : CHUNK_GRID, cnt * h.fam), dim3(256), 0, st, h, str,
 			(long)stream_stride);   // speculation and round 1 in one, fills the list of chunks to redo
 		int cur = 1;
-		for (int r = 2; r <= LINK_ROUNDS; ++r) {   // the lists shrink: fewer workgroups per shard after the first rounds
+		for (int r = 2; r <= link_rounds; ++r) {   // the lists shrink: fewer workgroups per shard after the first rounds
 			hipLaunchKernelGGL(k_link_work, dim3(LINK_SHARDS * (r <= 3 ? 4 : 1), cnt * h.fam), dim3(256), 0, st, h, str, (long)stream_stride, cur, r);
 			cur ^= 1;
 		}
