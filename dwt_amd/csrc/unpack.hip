@@ -442,6 +442,82 @@ __device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, 
 	return !dead;
 }
 
+// chunk_walk for visitors that never stop the walk (the table kernels, k_hopbits' stitched stretches).  The token loop has
+// no select at all: a lane whose token does not fit the 32-bit window still "takes" it — that carries it out of the
+// segment, hence out of the loop — and what the loop did for that token is taken back from copies before the 64-bit path
+// reads the token again: keep() copies the visitor's registers at the start of every token (moves: the cheap class of
+// profiles/r04_valu_peak.json, where the selects and carries they replace are of the dear one), undo() puts them back.
+// visit(run, neg, fits): whatever it does to memory must do nothing when `fits` is false; what it does to registers
+// need not care.  18 vector instructions per token for a counting visitor against 22.  Returns false for a dead path.
+template <class V, class K, class U>
+__device__ __forceinline__ bool chunk_walk_all(const ChunkWin &c, int &off, int &o, V &&visit, K &&keep, U &&undo)
+{
+	const unsigned d[6] = { (unsigned)c.w0, (unsigned)(c.w0 >> 32), (unsigned)c.w1, (unsigned)(c.w1 >> 32),
+		(unsigned)c.w2, (unsigned)(c.w2 >> 32) };
+	bool dead = false;
+#pragma unroll
+	for (int seg = 0; seg < CH_BITS / 32; ++seg) {
+		for (;;) {   // (uniform: once, and once more for every lane-token that did not fit its window)
+			const int bound = 32 * (seg + 1);
+			int len = 0, o_prev = o;
+			while (off < bound) {
+				o_prev = o;
+				keep();
+				const unsigned w32 = __builtin_amdgcn_alignbit(d[seg + 1], d[seg], (unsigned)off);
+				const int z = __builtin_ctz(w32 | 0x80000000u);
+				const int top = o + z;
+				len = z + top + 2;
+				visit(__builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o),
+					__builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u), len <= 32);
+				off += len;
+				o = (int)__builtin_elementwise_sub_sat((unsigned)top, 2u);
+			}
+			const bool slow = len > 32;
+			if (!ballot64(slow))
+				break;
+			if (slow) {
+				off -= len;
+				o = o_prev;
+				undo();
+				const int r = off & 31;
+				const unsigned long long lo64 = d[seg] | ((unsigned long long)d[seg + 1] << 32);
+				const unsigned long long w64 = r ? (lo64 >> r) | ((unsigned long long)d[seg + 2] << (64 - r)) : lo64;
+				int len64, next;
+				unsigned run, neg;
+				if (!token_at(w64, o, len64, run, neg, next)) {
+					dead = true;
+					off = 2 * CH_BITS + 64;   // past every bound: the lane only waits for the others now
+				} else {
+					visit(run, neg, true);
+					off += len64;
+					o = next;
+				}
+			}
+		}
+	}
+	return !dead;
+}
+
+// counting only: tokens and symbols (32 bits, saturating: a run is below 2^32, vli.h:86-101, and no segment asks for 2^31
+// symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over)
+__device__ __forceinline__ bool chunk_count(const ChunkWin &c, int &off, int &o, unsigned &tok, unsigned &sym)
+{
+	unsigned tok_prev = tok, sym_prev = sym;
+	return chunk_walk_all(c, off, o,
+		[&](unsigned run, unsigned, bool) {
+			sym = __builtin_elementwise_add_sat(sym, run + 1u);
+			++tok;
+		},
+		[&]() {
+			tok_prev = tok;
+			sym_prev = sym;
+		},
+		[&]() {
+			tok = tok_prev;
+			sym = sym_prev;
+		});
+}
+
 // The walker's own parse of the rest of one chunk: counts tokens and symbols from (off, o) until the
 // chunk ends, the next token's run would pass `need` symbols, or a token does not fit a 32-bit
 // window (the careful path takes that one).  All 64 lanes of the wave must be active and every
@@ -547,13 +623,8 @@ constexpr int LINK_SHARDS = 64;   // work lists are sharded: one counter would s
 constexpr int LINK_RUN = 8;       // chunks a thread of k_link_first parses one after the other (runs start at multiples of it)
 constexpr int RUN_W = 2 * LINK_RUN + 2;   // 64-bit LDS words per thread there
 
-// Symbols of a chunk are counted in 32 bits, saturating (a run is below 2^32, vli.h:86-101; no segment asks for 2^31
-// symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over).
-__device__ __forceinline__ unsigned sym_add(unsigned sym, unsigned run, bool counts)
-{
-	return __builtin_elementwise_add_sat(sym, counts ? run + 1u : 0u);
-}
-
+// (symbols of a chunk are counted in 32 bits, saturating: a run is below 2^32, vli.h:86-101, and no segment asks for 2^31
+// symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over)
 // returns true if the chunk's exit moved (its successor must be re-parsed)
 // (Round 4 tried to go on with the successor in the same thread while the exit moves, up to the end of the run of
 // LINK_RUN chunks: fewer rounds for the same reach — but reach is what hurts: paths that come out of the raw refinement
@@ -569,12 +640,7 @@ __device__ __forceinline__ bool link_parse(const DWork &w, const unsigned char *
 	if (in != 0xffff) {
 		const ChunkWin c = chunk_load((const unsigned long long *)(streams + img * stream_stride), stream_stride >> 3, ch);
 		int off = in & 0xff, o = in >> 8;
-		const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
-			tok += counts ? 1u : 0u;
-			sym = sym_add(sym, run, counts);
-			return true;
-		});
-		if (alive)
+		if (chunk_count(c, off, o, tok, sym))
 			out = (unsigned short)((off - CH_BITS) | (o << 8));
 	}
 	const unsigned short old = w.exitX[vs * w.NCH + ch];
@@ -669,11 +735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(64), amdgpu_wav
 				const unsigned short in = j == 0 || chunk == 0 || st == 0xffff ? start : st;
 				int off = in & 0xff, o = in >> 8;
 				unsigned sym = 0, tok = 0;
-				const bool alive = chunk_walk(c, off, o, [&](unsigned run, unsigned, bool counts) {
-					tok += counts ? 1u : 0u;
-					sym = sym_add(sym, run, counts);
-					return true;
-				});
+				const bool alive = chunk_count(c, off, o, tok, sym);
 				st = alive ? (unsigned short)((off - CH_BITS) | (o << 8)) : (unsigned short)0xffff;
 				rec = link_record(sym, tok, in, st);
 			}
@@ -1075,17 +1137,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 			unsigned roff = (unsigned)(seg0 + w.cs[vs * n + chunk] - (base_w << 4));   // symbols from the window's first one
 			const unsigned roff0 = roff;
 			unsigned *gp = sym + base_w;
-			chunk_walk(cw, off, o, [&](unsigned run, unsigned neg, bool counts) {
-				roff += counts ? run : 0u;
-				const unsigned wi = roff >> 4;
-				const unsigned bits = counts ? (1u | (neg << 1)) << ((roff & 15u) * 2u) : 0u;
-				if (wi < (unsigned)HB_WIN)
-					atomicOr(&win[wi], bits);
-				else if (counts)
-					atomicOr(gp + wi, bits);
-				roff += counts ? 1u : 0u;
-				return true;
-			});
+			unsigned roff_prev = roff;
+			chunk_walk_all(cw, off, o,
+				[&](unsigned run, unsigned neg, bool fits) {
+					roff += run;
+					const unsigned wi = roff >> 4;
+					const unsigned bits = fits ? (1u | (neg << 1)) << ((roff & 15u) * 2u) : 0u;
+					if (wi < (unsigned)HB_WIN)
+						atomicOr(&win[wi], bits);
+					else if (fits)
+						atomicOr(gp + wi, bits);
+					++roff;
+				},
+				[&]() { roff_prev = roff; }, [&]() { roff = roff_prev; });
 			if (roff > roff0) {
 				const unsigned lw = (roff - 1) >> 4;
 				atomicMax(&win_last, lw < (unsigned)HB_WIN - 1u ? lw : (unsigned)HB_WIN - 1u);
