@@ -357,6 +357,15 @@ __device__ __forceinline__ unsigned long long chunk_win(const ChunkWin &c, int o
 	return r ? (lo >> r) | (hi << (64 - r)) : lo;
 }
 
+// ((1 << width) - 1) << offset in one instruction (v_bfm_b32 takes five bits of each; the compiler spells the expression
+// with two shifts and a not)
+__device__ __forceinline__ unsigned bfm(unsigned width, unsigned offset)
+{
+	unsigned r;
+	asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset));
+	return r;
+}
+
 // one token of the pass-1 grammar at order o; false if it cannot be a token this codec wrote
 __device__ __forceinline__ bool token_at(unsigned long long win, int o, int &len, unsigned &run, unsigned &neg, int &next)
 {
@@ -411,7 +420,7 @@ __device__ __forceinline__ bool chunk_walk(const ChunkWin &c, int &off, int &o, 
 				const int len = z + top + 2;
 				fits = len <= 32;
 				// top remainder bits after the one, plus 2^top - 2^o = (2^z - 1) << o (bit-field extract / mask instructions)
-				const unsigned run = __builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o);
+				const unsigned run = __builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + bfm((unsigned)z, (unsigned)o);
 				const unsigned neg = __builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u);
 				go = visit(run, neg, fits);
 				const bool adv = fits && go;
@@ -467,7 +476,7 @@ __device__ __forceinline__ bool chunk_walk_all(const ChunkWin &c, int &off, int 
 				const int z = __builtin_ctz(w32 | 0x80000000u);
 				const int top = o + z;
 				len = z + top + 2;
-				visit(__builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + (((1u << z) - 1u) << o),
+				visit(__builtin_amdgcn_ubfe(w32, (unsigned)(z + 1), (unsigned)top) + bfm((unsigned)z, (unsigned)o),
 					__builtin_amdgcn_ubfe(w32, (unsigned)(len - 1), 1u), len <= 32);
 				off += len;
 				o = (int)__builtin_elementwise_sub_sat((unsigned)top, 2u);
@@ -502,18 +511,15 @@ __device__ __forceinline__ bool chunk_walk_all(const ChunkWin &c, int &off, int 
 // symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over)
 __device__ __forceinline__ bool chunk_count(const ChunkWin &c, int &off, int &o, unsigned &tok, unsigned &sym)
 {
-	unsigned tok_prev = tok, sym_prev = sym;
+	unsigned sym_prev = sym;
 	return chunk_walk_all(c, off, o,
 		[&](unsigned run, unsigned, bool) {
 			sym = __builtin_elementwise_add_sat(sym, run + 1u);
 			++tok;
 		},
+		[&]() { sym_prev = sym; },
 		[&]() {
-			tok_prev = tok;
-			sym_prev = sym;
-		},
-		[&]() {
-			tok = tok_prev;
+			--tok;
 			sym = sym_prev;
 		});
 }
