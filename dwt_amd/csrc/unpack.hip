@@ -2051,10 +2051,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
 	// 16 magnitude registers — extract, shift, or: 48 of the ~60 vector instructions a plane costs a lane.)
 	unsigned R[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	int p_last = 0, rows_in = 0;            // the plane of the row that came in last (halfword 0), rows so far; uniform
+	// (only the registers that hold rows move: rows_in is uniform, and with the eight or nine planes of an 8-bit picture the
+	// upper half of the register never does)
 	auto push_row = [&](unsigned row16) {
+		if (rows_in >= 8) {
 #pragma unroll
-		for (int k = 7; k >= 1; --k)
-			R[k] = __builtin_amdgcn_alignbit(R[k], R[k - 1], 16);
+			for (int k = 7; k >= 4; --k)
+				R[k] = __builtin_amdgcn_alignbit(R[k], R[k - 1], 16);
+		}
+		if (rows_in >= 6)
+			R[3] = __builtin_amdgcn_alignbit(R[3], R[2], 16);
+		if (rows_in >= 4)
+			R[2] = __builtin_amdgcn_alignbit(R[2], R[1], 16);
+		if (rows_in >= 2)
+			R[1] = __builtin_amdgcn_alignbit(R[1], R[0], 16);
 		R[0] = (R[0] << 16) | row16;
 		++rows_in;
 	};
@@ -2160,7 +2170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
 			const unsigned avail = r2 < n2done ? (n2done - r2 < cs ? n2done - r2 : cs) : 0u;
 			const unsigned rrel = ap_refbit[wv][p] + sb4;
 			const unsigned *rwp = ap_ref[q] + (rrel >> 5);
-			unsigned r16 = __builtin_amdgcn_alignbit(rwp[1], rwp[0], rrel & 31u) & ((1u << avail) - 1u);   // avail <= 16
+			unsigned r16 = __builtin_amdgcn_alignbit(rwp[1], rwp[0], rrel & 31u) & bfm(avail, 0u);   // avail <= 16
 			// four coefficients per look-up: symbols to the insignificant ones, refinement bits to the others, in order
 			const unsigned sig = valid16 & ~ins;
 			unsigned ones16 = 0, sgn16 = 0, ref16 = 0;
