@@ -39,7 +39,7 @@ WORKLOADS = {
     # name: (W, H, C, default frames per GPU per step)
     "gray4096": (4096, 4096, 1, 128),   # 64 frames until round 3; a part of the codec's four-part pipeline fills the chip better with 32 frames than with 16
     "rgb1080p": (1920, 1080, 3, 1024),  # configs[2]: 1024 frames per step, 6.4 G samples in one call each way
-    "rgb4096": (4096, 4096, 3, 32),
+    "rgb4096": (4096, 4096, 3, 64),
 }
 CONFIG_OF = {
     "gray4096": "BASELINE.json configs[1] geometry",

@@ -9,8 +9,8 @@ prof() { # name cmd...
 }
 tools/pmc_coder.sh 16 > $O/r04_coder_insts.json 2> $O/pmc_coder.err
 mkdir -p profiles && cp $O/r04_coder_insts.json profiles/r04_coder_insts.json   # (bench.py reads it for the instruction roofline)
-prof r04_bench_gray4096_64frames_kernel_stats python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-frames 0 --extras 0
-cp $O/r04_bench_gray4096_64frames_kernel_stats.out $O/r04_bench_line_under_rocprof.json
+prof r04_bench_gray4096_128frames_kernel_stats python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-frames 0 --extras 0
+cp $O/r04_bench_gray4096_128frames_kernel_stats.out $O/r04_bench_line_under_rocprof.json
 prof r04_lifting_only_64planes_kernel_stats python3 $GRAFT_REPO_ROOT/tools/time_lift.py 4096 64
 export DWTX_ONE_STREAM=1
 prof r04_codec_one_stream_gray4096_64frames_kernel_stats python3 $GRAFT_REPO_ROOT/tools/time_codec.py 4096 4096 1 64
