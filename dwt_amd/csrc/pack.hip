@@ -180,6 +180,13 @@ __device__ __forceinline__ unsigned wave_incl_add(unsigned v)
 }
 
 // vli.h:67-84 in closed form: order o, value v -> o* 
+// (1 << width) - 1 in one instruction (v_bfm_b32 takes five bits of the width; the compiler spells it with a shift and a not)
+__device__ __forceinline__ unsigned bfm_mask(unsigned width)
+{
+	unsigned r;
+	asm("v_bfm_b32 %0, %1, 0" : "=v"(r) : "v"(width));
+	return r;
+}
 __device__ __forceinline__ int vli_top(int o, unsigned v) { return ilog2u(v + (1u << o)); }
 __device__ __forceinline__ int vli_next(int top) { return top >= 2 ? top - 2 : 0; }
 
@@ -1598,6 +1605,13 @@ __device__ __forceinline__ void deposit_tokens_half(unsigned *rows, const HalfTo
 // a token pair holds an escape (run field 0xfff) / a break slot
 __device__ __forceinline__ bool pair_has_esc(unsigned x) { return (((x & 0x0fff0fffu) + 0x00010001u) & 0x10001000u) != 0u; }
 __device__ __forceinline__ bool pair_has_break(unsigned x) { return (x & (T_BREAK * 0x00010001u)) != 0u; }
+// ... an escape or a void slot (the padding of an image's last group): the pairs that leave the plain path of the order walks
+__device__ __forceinline__ bool pair_is_special(unsigned x)
+{
+	return ((((x & 0x0fff0fffu) + 0x00010001u) & 0x10001000u) | (x & (T_VOID * 0x00010001u))) != 0u;
+}
+// the order after a token of run v coded at order o (vli.h:67-84)
+__device__ __forceinline__ int vli_after(int o, unsigned v) { return (int)__builtin_elementwise_sub_sat((unsigned)vli_top(o, v), 2u); }
 
 __device__ __forceinline__ int vli_step(int o, unsigned v, bool skip)
 {
@@ -1647,13 +1661,13 @@ __device__ __forceinline__ int walk_order(const unsigned *my, const unsigned *bi
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const unsigned x = xs[h];
-			unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
-			if (pair_has_esc(x)) {
-				v0 = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
-				v1 = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			if (pair_is_special(x)) {
+				o = vli_step(o, token_run(x & 0xffffu, big, tb + 4 * q + 2 * h), x & T_VOID);
+				o = vli_step(o, token_run(x >> 16, big, tb + 4 * q + 2 * h + 1), (x >> 16) & T_VOID);
+			} else {   // (no select: a void slot would keep the order)
+				o = vli_after(o, x & T_RUN);
+				o = vli_after(o, (x >> 16) & T_RUN);
 			}
-			o = vli_step(o, v0, x & T_VOID);
-			o = vli_step(o, v1, (x >> 16) & T_VOID);
 		}
 	}
 	return o;
@@ -1671,6 +1685,25 @@ __device__ __forceinline__ void pair_bits(unsigned x, const unsigned (&v)[2], lo
 		const unsigned nb = (unsigned)(2 * top - o + 1) + ((tk & T_NOSIGN) ? 0u : 1u);
 		tokbits += (tk & T_VOID) ? 0u : nb;
 		o = (tk & T_VOID) ? o : vli_next(top);
+	}
+	if (pair_has_break(x) && count_raw) {
+#pragma unroll
+		for (int e = 0; e < 2; ++e)
+			if ((e ? x >> 16 : x) & T_BREAK)
+				rawbits += srefs[find_break_seg(btok, K, (unsigned)(t + e))];
+	}
+}
+
+// the same for a pair without escapes and void slots: no selects
+__device__ __forceinline__ void pair_bits_plain(unsigned x, long t, int &o, bool count_raw,
+	const unsigned *btok, const unsigned *srefs, int K, unsigned &tokbits, unsigned long long &rawbits)
+{
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const unsigned tk = e ? x >> 16 : x & 0xffffu;
+		const int top = vli_top(o, tk & T_RUN);
+		tokbits += (unsigned)(2 * top - o + 2) - ((tk >> 15) & 1u);   // T_NOSIGN: one bit less
+		o = (int)__builtin_elementwise_sub_sat((unsigned)top, 2u);
 	}
 	if (pair_has_break(x) && count_raw) {
 #pragma unroll
@@ -1703,15 +1736,17 @@ __device__ __forceinline__ int walk_order2(const unsigned *my, const unsigned *b
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
 				const unsigned x = xs[h];
-				unsigned v0 = x & T_RUN, v1 = (x >> 16) & T_RUN;
-				if (pair_has_esc(x)) {
-					v0 = token_run(x & 0xffffu, big, tb + 4 * (q + qq) + 2 * h);
-					v1 = token_run(x >> 16, big, tb + 4 * (q + qq) + 2 * h + 1);
+				if (pair_is_special(x)) {
+					const unsigned v0 = token_run(x & 0xffffu, big, tb + 4 * (q + qq) + 2 * h);
+					const unsigned v1 = token_run(x >> 16, big, tb + 4 * (q + qq) + 2 * h + 1);
+					lo = vli_step(lo, v0, x & T_VOID);
+					hi = vli_step(hi, v0, x & T_VOID);
+					lo = vli_step(lo, v1, (x >> 16) & T_VOID);
+					hi = vli_step(hi, v1, (x >> 16) & T_VOID);
+				} else {
+					lo = vli_after(vli_after(lo, x & T_RUN), (x >> 16) & T_RUN);
+					hi = vli_after(vli_after(hi, x & T_RUN), (x >> 16) & T_RUN);
 				}
-				lo = vli_step(lo, v0, x & T_VOID);
-				hi = vli_step(hi, v0, x & T_VOID);
-				lo = vli_step(lo, v1, (x >> 16) & T_VOID);
-				hi = vli_step(hi, v1, (x >> 16) & T_VOID);
 			}
 		}
 	}
@@ -1722,12 +1757,12 @@ __device__ __forceinline__ int walk_order2(const unsigned *my, const unsigned *b
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const unsigned x = xs[h];
-			unsigned v[2] = { x & T_RUN, (x >> 16) & T_RUN };
-			if (pair_has_esc(x)) {
-				v[0] = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
-				v[1] = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			if (pair_is_special(x)) {
+				const unsigned v[2] = { token_run(x & 0xffffu, big, tb + 4 * q + 2 * h), token_run(x >> 16, big, tb + 4 * q + 2 * h + 1) };
+				pair_bits(x, v, tb + 4 * q + 2 * h, lo, count_raw, btok, srefs, K, tokbits, rawbits);
+			} else {
+				pair_bits_plain(x, tb + 4 * q + 2 * h, lo, count_raw, btok, srefs, K, tokbits, rawbits);
 			}
-			pair_bits(x, v, tb + 4 * q + 2 * h, lo, count_raw, btok, srefs, K, tokbits, rawbits);
 		}
 	}
 	if (met)
@@ -1746,12 +1781,12 @@ __device__ __forceinline__ void walk_bits(const unsigned *my, const unsigned *bi
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const unsigned x = xs[h];
-			unsigned v[2] = { x & T_RUN, (x >> 16) & T_RUN };
-			if (pair_has_esc(x)) {
-				v[0] = token_run(x & 0xffffu, big, tb + 4 * q + 2 * h);
-				v[1] = token_run(x >> 16, big, tb + 4 * q + 2 * h + 1);
+			if (pair_is_special(x)) {
+				const unsigned v[2] = { token_run(x & 0xffffu, big, tb + 4 * q + 2 * h), token_run(x >> 16, big, tb + 4 * q + 2 * h + 1) };
+				pair_bits(x, v, tb + 4 * q + 2 * h, o, count_raw, btok, srefs, K, tokbits, rawbits);
+			} else {
+				pair_bits_plain(x, tb + 4 * q + 2 * h, o, count_raw, btok, srefs, K, tokbits, rawbits);
 			}
-			pair_bits(x, v, tb + 4 * q + 2 * h, o, count_raw, btok, srefs, K, tokbits, rawbits);
 		}
 	}
 }
@@ -2101,20 +2136,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 			fill = (int)(next & 31);
 		}
 	};
-	// one token whose code is at most 16 bits (order <= 7, run < 128, not a break slot): no branches
+	// one token whose code is at most 16 bits (order <= 7, run < 128, neither a break slot nor a void one — the padding of an
+	// image's last group goes the general way): no branches, no selects
 	auto code16 = [&](unsigned tk, unsigned &code, int &len) {
 		const unsigned s = (tk & T_RUN) + (1u << o);
 		const int top = 31 - __builtin_clz(s);
 		const int z = top - o;
-		const unsigned rem = s & ((1u << top) - 1u);
-		unsigned c = (rem << (z + 1)) | (1u << z);
-		int l = z + 1 + top;
-		c |= ((tk >> 12) & 1u) << l;
-		l += (tk & T_NOSIGN) ? 0 : 1;
-		const bool vd = (tk & T_VOID) != 0u;
-		code = vd ? 0u : c;
-		len = vd ? 0 : l;
-		o = vd ? o : (top >= 2 ? top - 2 : 0);
+		const unsigned rem = s & bfm_mask((unsigned)top);
+		const int l = z + 1 + top;
+		code = (rem << (z + 1)) | (1u << z) | (((tk >> 12) & 1u) << l);
+		len = l + ((tk & T_NOSIGN) ? 0 : 1);
+		o = (int)__builtin_elementwise_sub_sat((unsigned)top, 2u);
 	};
 	HalfTokens staged = load_tokens_half(tok16, wave * CHUNK, T, lane, 0);
 	for (int half = 0; half < 2; ++half) {   // (uniform: every lane of the wave takes part in the staging)
@@ -2135,7 +2167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 			for (int h = 0; h < 2; ++h) {
 				const unsigned x = xs[h];
 				// run >= 128 (escapes too) or a break slot in the pair, or a high order: the general path
-				if ((x & (0x0f80u * 0x00010001u | T_BREAK * 0x00010001u)) != 0u || o > 7) {
+				if ((x & ((0x0f80u | T_BREAK | T_VOID) * 0x00010001u)) != 0u || o > 7) {
 					slow_token(x & 0xffffu, tb + 4 * q + 2 * h);
 					slow_token(x >> 16, tb + 4 * q + 2 * h + 1);
 				} else {
