@@ -171,3 +171,35 @@ def test_streams_the_single_path_family_cannot_follow(ctx, sign, opts):
     opts.set("two_families", 1)   # both families from the start: the path the fallback takes
     back, infos = ctx.decode_planes(streams, W, H, 1)
     assert (back.cpu().numpy() == np.concatenate(variants)).all()
+
+
+def test_second_walk_takes_only_the_images_that_gave_up(ctx, opts):
+    """A batch of 26 streams — four parts — of which three (two of them neighbours, in different parts) lock the parity:
+    only those are walked again with both families (dwtx_decode_planes_ex: run by run of consecutive images), the others
+    keep their first walk; every plane must come back exactly, in both modes of running the batch."""
+    import torch
+
+    W = H = 512
+    rng = np.random.default_rng(26)
+    levels, lengths, pixels, _, _ = __import__("dwt_amd").compute_lengths(W, H)
+    planes = []
+    for i in range(26):
+        if i in (5, 6, 19):
+            planes.append(_parity_locked_planes(W, H, 1 if i != 6 else -1, 0))
+        else:
+            lin = np.zeros((1, W * H), dtype=np.int32)
+            n = pixels[levels]
+            lin[0, :n] = (rng.laplace(0.0, 3.0 + i, n)).astype(np.int32)
+            planes.append(lin)
+    streams = [orc.encode_lin(lin, W, H)[0] for lin in planes]
+    want = np.concatenate(planes)
+    for one_stream in (0, 1):
+        opts.set("one_stream", one_stream)
+        back, infos = ctx.decode_planes(streams, W, H, 1)
+        assert all(i.status == 0 and not i.truncated for i in infos)
+        assert (back.cpu().numpy() == want).all()
+    opts.set("one_stream", 0)
+    opts.set("no_second_walk", 1)
+    with pytest.raises(__import__("dwt_amd").DwtxError):   # (the locked ones really do give up)
+        ctx.decode_planes(streams, W, H, 1)
+
