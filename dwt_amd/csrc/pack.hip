@@ -2086,8 +2086,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 		if (!v)
 			return;
 		const unsigned long rel = (unsigned long)(wi - wbase);
+		// (the LDS word through a pointer that says so: with two plain pointers the compiler joins the branches into one
+		// flat atomic on a selected 64-bit address — ten vector instructions per word)
 		if (rel < (unsigned long)EWIN)
-			atomicOr(&win[rel], v);
+			__hip_atomic_fetch_or((__attribute__((address_space(3))) unsigned *)win + rel, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		else if (wi < out_words)
 			atomicOr(dst + wi, v);
 	};
