@@ -616,22 +616,16 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 // kernels run a capped grid whose workgroups stride over the virtual blocks of 256 chunks that hold data.
 constexpr int CHUNK_GRID = 2048;
 
-// One refinement round: parse chunk i from the state in which the previous
-// round's path left chunk i-1.  After r rounds the entry state of a chunk is what
-// a parse started r chunks earlier (at order 0) arrives with, so it agrees with
-// any other path that has been running for a while.  The last round records the
-// token/symbol counts and whether the exit still moved ("unjoined").
 // Refinement by relaxation: (re-)parse chunk `ch` from the state its predecessor's recorded path
 // currently leaves in; if that moves this chunk's own exit, the successor is queued for the next
-// round.  Only the first round touches every chunk; afterwards a few percent, then a few per mille.
-// After r rounds a chunk's entry state is what a parse started r chunks earlier arrives with.
+// round.  The first round (k_link_first) touches every chunk — in runs of LINK_RUN, one after the other —
+// and queues the runs' first chunks whose warm-up had not met the run before; afterwards a percent of
+// the chunks, then a few per mille.
 constexpr int LINK_SHARDS = 64;   // work lists are sharded: one counter would serialise the appends in L2
 constexpr int LINK_RUN = 8;       // chunks a thread of k_link_first parses one after the other (runs start at multiples of it)
 constexpr int RUN_W = 2 * LINK_RUN + 2;   // 64-bit LDS words per thread there
 
-// (symbols of a chunk are counted in 32 bits, saturating: a run is below 2^32, vli.h:86-101, and no segment asks for 2^31
-// symbols — a ring has at most 2^30 coefficients — so a chunk at the ceiling is simply never hopped over)
-// returns true if the chunk's exit moved (its successor must be re-parsed)
+// Returns true if the chunk's exit moved (its successor must be re-parsed).
 // (Round 4 tried to go on with the successor in the same thread while the exit moves, up to the end of the run of
 // LINK_RUN chunks: fewer rounds for the same reach — but reach is what hurts: paths that come out of the raw refinement
 // blocks then run 8 times as far into the first-pass stretches and replace records that were right; the walker's hops
