@@ -10,7 +10,8 @@
 //               out for the stream stride but worked on only that far).
 //   k_peek + k_clear_bitmaps  the plane counts of every stream's preamble bound how much of
 //               its symbol bitmap can be used: only that much is cleared.
-//   k_link_first/k_link_work/k_scan_*  speculative 128-bit chunk parse that lets the walker jump
+//   k_link_first/k_link_work/k_scan_*  speculative 128-bit chunk parse (a thread parses a run of eight chunks
+//               one after the other, then relaxation rounds repair the runs' seams) that lets the walker jump
 //               over stitched stretches of the stream (see below): one family of
 //               recorded paths, two (even / odd start) for a part of the batch whose
 //               walk gives up on a parity-locked stretch (k_part_reset).
