@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	// chunk i is safe to parse blindly if every token starting in it ends inside the data
 	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
 #ifdef DWTX_DEBUG_HOOKS   // cycle counters for tools/dbg_walker.py (s_memtime waits on the scalar memory counter: not in the product)
-	unsigned long long t_hop = 0, t_fast = 0, t_all0 = __builtin_readcyclecounter(), t_mark = 0;
+	unsigned long long t_hop = 0, t_fast = 0, t_load = 0, t_scan = 0, t_all0 = __builtin_readcyclecounter(), t_mark = 0;
 #define WALK_MARK() t_mark = __builtin_readcyclecounter()
 #define WALK_ADD(acc) do { const unsigned long long t_now = __builtin_readcyclecounter(); acc += t_now - t_mark; t_mark = t_now; } while (0)
 #else
@@ -1555,7 +1555,15 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							giveup = true;
 							return false;
 						}
-						const ChunkScan cs = chunk_scan(chunk_load(s64, br.n64, ci), rel, order, need);
+						const ChunkWin cwv = chunk_load(s64, br.n64, ci);
+#ifdef DWTX_DEBUG_HOOKS
+						asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+						WALK_ADD(t_load);
+#endif
+						const ChunkScan cs = chunk_scan(cwv, rel, order, need);
+#ifdef DWTX_DEBUG_HOOKS
+						WALK_ADD(t_scan);
+#endif
 						const unsigned tok = cs.tok, sym = cs.sym;
 						const int off = cs.off, o = cs.o;
 						if (tok) {
@@ -1686,7 +1694,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.walked_tokens = walked;
 	I.zeros_left = cnt;
 #ifdef DWTX_DEBUG_HOOKS
-	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast; w.dbg[img * 4 + 3] = scans; }
+	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast | (t_load << 32); w.dbg[img * 4 + 3] = scans | (t_scan << 32); }
 #endif
 	I.level = level;
 	I.nsegs = nsegs;

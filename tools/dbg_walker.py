@@ -19,4 +19,5 @@ d = dbg.cpu()
 for k, i in enumerate(infos[:4]):
     # shader clock cycles (s_memtime)
     print("hops", i.hops, "hopped_chunks", i.hopped_chunks, "walked_tokens", i.walked_tokens, "nsegs", i.nsegs,
-          "cycles all/hop/fast", d[k, 0].item(), d[k, 1].item(), d[k, 2].item(), "n_fast", d[k, 3].item())
+          "cycles all/hop/records after the scan", d[k, 0].item(), d[k, 1].item(), d[k, 2].item() & 0xffffffff, "chunk load", d[k, 2].item() >> 32,
+          "chunk_scan", d[k, 3].item() >> 32, "chunks by hand", d[k, 3].item() & 0xffffffff)
