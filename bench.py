@@ -138,10 +138,12 @@ class Runner:
         self.rank, self.world, self.dev = rank, world, dev
         self.pix = ctx.synth_pixels(B, H, W, C, seed0=rank * B, kind=0)      # resident in HBM before the timed region
         self.stride = ctx.lib.dwtx_encode_bound(W, H, C)
-        if B * self.stride > (8 << 30):
-            # The worst-case bound (3 bytes per sample) times a thousand frames is tens of gigabytes of output rows, and the
-            # decoder's chunk tables are laid out per stride: rows sized from the streams of a few probe frames, half as
-            # much again (a stream that did not fit would be clipped like a CAPACITY and fail the lossless check below)
+        if B * self.stride > (2 << 30):
+            # The worst-case bound (3 bytes per sample) times the batch is gigabytes of output rows (tens of them for a thousand
+            # frames), and the decoder's chunk tables are laid out per stride (45 GB for 128 gray frames at the bound, 11 GB
+            # this way; the speed is the same either way, tools/time_codec.py TIGHT_STRIDE=1): rows sized from the streams of a
+            # few probe frames, half as much again (a stream that did not fit would be clipped like a CAPACITY and fail the
+            # lossless check below)
             probe, pinfo = ctx.encode_device(self.pix[:8])
             self.stride = (int(ctx.stream_lengths(pinfo).max().item()) * 3 // 2 + 64 + 7) // 8 * 8
             del probe, pinfo
