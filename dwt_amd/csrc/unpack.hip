@@ -551,7 +551,10 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 	// overshoot of the segment (once per segment) just sends the chunk to the checked loop below.
 	{
 		const int zA = winA ? __builtin_ctz(winA) : 32, zB = winB ? __builtin_ctz(winB) : 32;
-		int ordA = -1, ordB = -1, offf = off, of = o, worst = 0;
+		// (the chain's state is uniform and is told so: left to itself the compiler kept it in vector registers — a
+		// v_readfirstlane and a v_readlane per token, 16 instructions of which every one waits for the one before; from
+		// scalar registers the chain is one v_readlane and four scalar instructions long)
+		int ordA = -1, ordB = -1, offf = __builtin_amdgcn_readfirstlane(off), of = __builtin_amdgcn_readfirstlane(o), worst = 0;
 		while (offf < 64) {
 			const int z = __builtin_amdgcn_readlane(zA, offf);
 			const int top = of + z;
@@ -591,7 +594,12 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 			}
 		}
 	}
-	unsigned tok = 0, left = need;   // left = symbols the segment still takes
+	// (the checked loop takes the last chunk of every segment — its tokens run past what the segment needs — so it gets the
+	// same treatment: its state is told to be uniform and stays on the scalar unit)
+	const unsigned need_s = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+	unsigned tok = 0, left = need_s;   // left = symbols the segment still takes
+	off = __builtin_amdgcn_readfirstlane(off);
+	o = __builtin_amdgcn_readfirstlane(o);
 	// branch-free token step (single-exit loops keep the scalar code tight); false = stop at this token
 	auto token = [&](unsigned w32) -> bool {
 		const int z = w32 ? __builtin_ctz(w32) : 32;
@@ -609,7 +617,7 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 		ok = token((unsigned)__builtin_amdgcn_readlane((int)winA, off));
 	while (ok && off < 128)
 		ok = token((unsigned)__builtin_amdgcn_readlane((int)winB, off - 64));
-	ChunkScan r = { tok, need - left, off, o };
+	ChunkScan r = { tok, need_s - left, off, o };
 	return r;
 }
 
