@@ -525,6 +525,18 @@ __device__ __forceinline__ bool chunk_count(const ChunkWin &c, int &off, int &o,
 		});
 }
 
+// inclusive prefix sum over the 64 lanes (DPP row shifts and broadcasts)
+__device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
+{
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+	return v;
+}
+
 // The walker's own parse of the rest of one chunk: counts tokens and symbols from (off, o) until the
 // chunk ends, the next token's run would pass `need` symbols, or a token does not fit a 32-bit
 // window (the careful path takes that one).  All 64 lanes of the wave must be active and every
@@ -554,23 +566,30 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 		// (the chain's state is uniform and is told so: left to itself the compiler kept it in vector registers — a
 		// v_readfirstlane and a v_readlane per token, 16 instructions of which every one waits for the one before; from
 		// scalar registers the chain is one v_readlane and four scalar instructions long)
-		int ordA = -1, ordB = -1, offf = __builtin_amdgcn_readfirstlane(off), of = __builtin_amdgcn_readfirstlane(o), worst = 0;
+		// Eleven instructions per token: the state carried is the order plus two (the token's length is 2z + o + 2), and whether
+		// every token fits its window is looked at afterwards, by all lanes at once.  (A v_writelane for the order of the
+		// token's lane would save two more, but takes its lane through m0, which is not ours to clobber.)
+		int ordA = -1, ordB = -1, offf = __builtin_amdgcn_readfirstlane(off), of2 = __builtin_amdgcn_readfirstlane(o) + 2;
 		while (offf < 64) {
 			const int z = __builtin_amdgcn_readlane(zA, offf);
-			const int top = of + z;
-			worst = max(worst, z + top);
-			ordA = lane == offf ? of : ordA;
-			offf += z + top + 2;
-			of = max(top, 2) - 2;
+			ordA = lane == offf ? of2 : ordA;
+			const int top2 = of2 + z;
+			offf += top2 + z;
+			of2 = max(top2 - 2, 2);
 		}
 		while (offf < 128) {
 			const int z = __builtin_amdgcn_readlane(zB, offf - 64);
-			const int top = of + z;
-			worst = max(worst, z + top);
-			ordB = lane == offf - 64 ? of : ordB;
-			offf += z + top + 2;
-			of = max(top, 2) - 2;
+			ordB = lane == offf - 64 ? of2 : ordB;
+			const int top2 = of2 + z;
+			offf += top2 + z;
+			of2 = max(top2 - 2, 2);
 		}
+		const int of = of2 - 2;
+		ordA = ordA < 0 ? -1 : ordA - 2;
+		ordB = ordB < 0 ? -1 : ordB - 2;
+		// z + top of the longest token met (tokens of lanes never visited do not count)
+		const bool longA = ordA >= 0 && 2 * zA + ordA > 30, longB = ordB >= 0 && 2 * zB + ordB > 30;
+		const int worst = ballot64(longA || longB) ? 31 : 0;
 		if (worst <= 30) {
 			constexpr unsigned CAP = 1u << 24;   // 128 tokens of at most this many symbols cannot overflow
 			auto cost = [&](unsigned win, int z, int ord) -> unsigned {
@@ -590,6 +609,36 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 				__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 			if (!capped && symf <= need) {
 				ChunkScan r = { (unsigned)(__builtin_popcountll(visA) + __builtin_popcountll(visB)), symf, offf, of };
+				return r;
+			}
+			if (!capped) {
+				// The chunk holds more than the segment still takes (its last chunk, once per segment): the tokens that
+				// fit are those whose running sum stays within `need` — two prefix sums over the lanes instead of the
+				// checked loop's second, serial walk — and the walk goes on at the first token that does not fit
+				// (its offset is its lane, its order is in that lane).
+				const unsigned need_s = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+				const unsigned pA = wave_incl_add_u(cA);
+				const unsigned totA = (unsigned)__builtin_amdgcn_readlane((int)pA, 63);
+				const unsigned pB = totA + wave_incl_add_u(cB);
+				const unsigned long long fitA = ballot64(ordA >= 0 && pA <= need_s), fitB = ballot64(ordB >= 0 && pB <= need_s);
+				const unsigned long long restA = visA & ~fitA, restB = visB & ~fitB;
+				// (the sums only grow: the fitting tokens come first, so fitB is empty unless all of A's fit)
+				unsigned sym = 0;
+				if (fitB)
+					sym = (unsigned)__builtin_amdgcn_readlane((int)pB, 63 - __builtin_clzll(fitB));
+				else if (fitA)
+					sym = (unsigned)__builtin_amdgcn_readlane((int)pA, 63 - __builtin_clzll(fitA));
+				int off2, o2;
+				if (restA) {
+					const int at = __builtin_ctzll(restA);
+					off2 = at;
+					o2 = __builtin_amdgcn_readlane(ordA, at);
+				} else {   // (restB is not empty: the whole chunk did not fit)
+					const int at = __builtin_ctzll(restB);
+					off2 = 64 + at;
+					o2 = __builtin_amdgcn_readlane(ordB, at);
+				}
+				ChunkScan r = { (unsigned)(__builtin_popcountll(fitA) + __builtin_popcountll(fitB)), sym, off2, o2 };
 				return r;
 			}
 		}
@@ -2014,17 +2063,6 @@ __device__ const DepositTables DEPOSIT = make_deposit_tables();
 struct __attribute__((packed, aligned(4))) Int4S {
 	int x, y, z, w;
 };
-
-__device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
-{
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
-	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
-	return v;
-}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_apply_all(UnpackGeom g, DWork w, const unsigned char *streams, long stream_stride, int *lin)
 {
