@@ -545,6 +545,10 @@ __device__ __forceinline__ unsigned wave_incl_add_u(unsigned v)
 struct ChunkScan {
 	unsigned tok, sym;
 	int off, o;
+	// the token at (off, o) is the one whose run outlives the segment (rle.h:95-101 carries it on): its run, the bits of its
+	// code without the sign (the one it ends lies in a later segment) and the order after it; cross_bits = 0: not known
+	unsigned cross_run;
+	int cross_bits, cross_o;
 };
 
 __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int o, unsigned need)
@@ -608,7 +612,7 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 			const unsigned symf = (unsigned)(__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
 				__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 			if (!capped && symf <= need) {
-				ChunkScan r = { (unsigned)(__builtin_popcountll(visA) + __builtin_popcountll(visB)), symf, offf, of };
+				ChunkScan r = { (unsigned)(__builtin_popcountll(visA) + __builtin_popcountll(visB)), symf, offf, of, 0u, 0, 0 };
 				return r;
 			}
 			if (!capped) {
@@ -628,17 +632,24 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 					sym = (unsigned)__builtin_amdgcn_readlane((int)pB, 63 - __builtin_clzll(fitB));
 				else if (fitA)
 					sym = (unsigned)__builtin_amdgcn_readlane((int)pA, 63 - __builtin_clzll(fitA));
-				int off2, o2;
+				int off2, o2, z2;
+				unsigned c2;
 				if (restA) {
 					const int at = __builtin_ctzll(restA);
 					off2 = at;
 					o2 = __builtin_amdgcn_readlane(ordA, at);
+					z2 = __builtin_amdgcn_readlane(zA, at);
+					c2 = (unsigned)__builtin_amdgcn_readlane((int)cA, at);
 				} else {   // (restB is not empty: the whole chunk did not fit)
 					const int at = __builtin_ctzll(restB);
 					off2 = 64 + at;
 					o2 = __builtin_amdgcn_readlane(ordB, at);
+					z2 = __builtin_amdgcn_readlane(zB, at);
+					c2 = (unsigned)__builtin_amdgcn_readlane((int)cB, at);
 				}
-				ChunkScan r = { (unsigned)(__builtin_popcountll(fitA) + __builtin_popcountll(fitB)), sym, off2, o2 };
+				// that token is the one that runs past the segment's end (its cost is its run + 1, not capped here)
+				const int top2 = o2 + z2;
+				ChunkScan r = { (unsigned)(__builtin_popcountll(fitA) + __builtin_popcountll(fitB)), sym, off2, o2, c2 - 1u, z2 + top2 + 1, max(top2, 2) - 2 };
 				return r;
 			}
 		}
@@ -666,7 +677,7 @@ __device__ __forceinline__ ChunkScan chunk_scan(const ChunkWin &c, int off, int 
 		ok = token((unsigned)__builtin_amdgcn_readlane((int)winA, off));
 	while (ok && off < 128)
 		ok = token((unsigned)__builtin_amdgcn_readlane((int)winB, off - 64));
-	ChunkScan r = { tok, need_s - left, off, o };
+	ChunkScan r = { tok, need_s - left, off, o, 0u, 0, 0 };
 	return r;
 }
 
@@ -1638,6 +1649,20 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 							br.b = ((unsigned long long)ci << CH_LOG2) + (unsigned)off;
 							br_synced = false;
 							moved = true;
+						}
+						if (cs.cross_bits && q < n1) {   // (q == n1: the tokens that fit end the pass exactly, what follows is not this segment's)
+							// The next token's run outlives this segment's first pass, and chunk_scan has it: what the careful path
+							// below does with such a token (it reads the code, not the sign: the one that ends the run lies in a
+							// later segment), without filling the bit reader again for it.
+							const unsigned rem = (unsigned)(n1 - q);
+							++walked;
+							order = cs.cross_o;
+							br.b = ((unsigned long long)ci << CH_LOG2) + (unsigned)off + (unsigned)cs.cross_bits;
+							br_synced = false;
+							q = n1;
+							cnt = cs.cross_run - rem + 1;
+							WALK_ADD(t_fast);
+							break;
 						}
 					}
 					WALK_ADD(t_fast);
