@@ -1443,7 +1443,9 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	int planes[3] = { 0, 0, 0 };
 	int pmax = 0;
 	int nonsig_own[1] = { 0 };   // SEG: the one counter this segment needs
-	int *nonsig = w.nonsig + (long)img * 48;
+	// The serial walk's 48 counters (channel x level) live in the lanes of one register: read with v_readlane, written with a
+	// select.  (In memory — until round 4 — every segment began by waiting for a load of its counter: 70 round trips per frame.)
+	int nonsig_v = 0;
 	SegIndex *idx = w.idx + (long)img * MAX_SEGS;
 	if (!SEG) {
 		info_begin(I, g);
@@ -1460,9 +1462,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		for (int c = 0; c < g.C; ++c)
 			for (int l = 0; l < g.levels; ++l)
 				I.missing[c * 16 + l] = planes[c];
-		for (int c = 0; c < g.C; ++c)
-			for (int l = 0; l < g.levels; ++l)
-				nonsig[c * 16 + l] = g.pixels[l + 1] - g.pixels[l];
+		{
+			const int lv = (int)threadIdx.x & 15, ch = (int)threadIdx.x >> 4;   // this lane's (channel, level)
+			nonsig_v = ch < g.C && lv < g.levels ? g.pixels[lv + 1] - g.pixels[lv] : 0;
+		}
 	} else {
 		br.w = (const unsigned long long *)s8;
 		br.n64 = stream_stride >> 3;
@@ -1498,7 +1501,7 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	// chunk i is safe to parse blindly if every token starting in it ends inside the data
 	const long lastsafe = br.end_bits >= 64 + CH_BITS ? (long)((br.end_bits - 64) >> CH_LOG2) - 1 : -1;
 #ifdef DWTX_DEBUG_HOOKS   // cycle counters for tools/dbg_walker.py (s_memtime waits on the scalar memory counter: not in the product)
-	unsigned long long t_hop = 0, t_fast = 0, t_load = 0, t_scan = 0, t_all0 = __builtin_readcyclecounter(), t_mark = 0;
+	unsigned long long t_hop = 0, t_fast = 0, t_load = 0, t_scan = 0, t_care = 0, n_care = 0, t_all0 = __builtin_readcyclecounter(), t_mark = 0;
 #define WALK_MARK() t_mark = __builtin_readcyclecounter()
 #define WALK_ADD(acc) do { const unsigned long long t_now = __builtin_readcyclecounter(); acc += t_now - t_mark; t_mark = t_now; } while (0)
 #else
@@ -1524,8 +1527,8 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	// decode.c:67-100 without touching coefficients; false = stop decoding (decode.c:204,221,238)
 	auto segment = [&](int c, int l, int p) -> bool {
 		const int num = g.pixels[l + 1] - g.pixels[l];
-		int &left = SEG ? nonsig_own[0] : nonsig[c * 16 + l];   // coefficients of this (channel, level) still insignificant
-		const int n1 = p < 0 ? num : left;
+		// coefficients of this (channel, level) still insignificant
+		const int n1 = p < 0 ? num : SEG ? nonsig_own[0] : __builtin_amdgcn_readlane(nonsig_v, c * 16 + l);
 		const int n2 = num - n1;
 		const int k = nsegs++;
 		const unsigned long long sym0 = symtotal;
@@ -1669,6 +1672,10 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 					if (moved)
 						continue;
 				}
+#ifdef DWTX_DEBUG_HOOKS
+				WALK_MARK();
+				++n_care;
+#endif
 				if (!br_synced) {
 					br.seek(br.b);
 					br_synced = true;
@@ -1682,6 +1689,9 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 				}
 				++walked;
 				zr = v;
+#ifdef DWTX_DEBUG_HOOKS
+				WALK_ADD(t_care);
+#endif
 			} else {
 				zr = cnt - 1;
 			}
@@ -1711,8 +1721,12 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 				bm.set_sign(sym0 + (unsigned)q);
 			++q;
 		}
-		if (p >= 0)
-			left = n1 - ones;
+		if (p >= 0) {
+			if (SEG)
+				nonsig_own[0] = n1 - ones;
+			else
+				nonsig_v = wl == c * 16 + l ? n1 - ones : nonsig_v;
+		}
 		if (!ok)
 			return false;
 		if (p >= 0 && n2 > 0) {
@@ -1776,7 +1790,8 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 	I.walked_tokens = walked;
 	I.zeros_left = cnt;
 #ifdef DWTX_DEBUG_HOOKS
-	if (w.dbg) { w.dbg[img * 4 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 4 + 1] = t_hop; w.dbg[img * 4 + 2] = t_fast | (t_load << 32); w.dbg[img * 4 + 3] = scans | (t_scan << 32); }
+	if (w.dbg) { w.dbg[img * 8 + 0] = __builtin_readcyclecounter() - t_all0; w.dbg[img * 8 + 1] = t_hop; w.dbg[img * 8 + 2] = t_fast; w.dbg[img * 8 + 3] = scans;
+		w.dbg[img * 8 + 4] = t_load; w.dbg[img * 8 + 5] = t_scan; w.dbg[img * 8 + 6] = t_care; w.dbg[img * 8 + 7] = n_care; }
 #endif
 	I.level = level;
 	I.nsegs = nsegs;
@@ -2603,7 +2618,7 @@ int dwtx_decode_planes_ex(dwtx_ctx *ctx, int32_t *lin, int32_t *pyr, const uint8
 		h.idx_nsegs += i0;
 		h.seg_slot += (size_t)i0 * (MAX_SEGS + 1);
 		if (h.dbg)
-			h.dbg += (size_t)i0 * 4;
+			h.dbg += (size_t)i0 * 8;
 		return h;
 	};
 	// chunk tables; then (walk) token walk and symbol bits of the hopped-over chunks
