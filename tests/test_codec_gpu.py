@@ -700,3 +700,20 @@ def test_decode_with_two_levels_per_pass_and_without(ctx, shape, opts):
             opts.set("no_fused_levels", off)
             got = ctx.decode(blobs)
             assert all(g.shape == w.shape and (g == w).all() for g, w in zip(got, want)), (off, blobs is cuts)
+
+
+def test_benchmark_frames_with_a_long_stretch_of_hand_parsed_chunks_take_the_first_walk(ctx, opts):
+    """Frames 181 and 182 of the benchmark's synthetic sequence hold a stretch of 49..128 chunks in a row that the one-family
+    token walk parses by hand.  Under the walk's earlier patience (48 in a row) they took the second, two-family walk — and
+    their part of the batch with them, 40 % of a 192-frame batch's decoding time.  They must come back
+    exactly, and without the second walk."""
+    import torch
+
+    W = H = 4096
+    pix = ctx.synth_pixels(4, H, W, 1, seed0=180, kind=0)   # frames 180..183 (a batch of four: one family from the start)
+    streams, info = ctx.encode_device(pix)
+    lens = ctx.stream_lengths(info)
+    opts.set("no_second_walk", 1)   # a walk that gives up is an error now
+    out, infos = ctx.decode_device(streams, lens, W, H, 1)
+    assert all(i.status == 0 and not i.truncated for i in infos)
+    assert torch.equal(out.view(4, H, W, 1), pix)
