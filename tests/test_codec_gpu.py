@@ -717,3 +717,33 @@ def test_benchmark_frames_with_a_long_stretch_of_hand_parsed_chunks_take_the_fir
     out, infos = ctx.decode_device(streams, lens, W, H, 1)
     assert all(i.status == 0 and not i.truncated for i in infos)
     assert torch.equal(out.view(4, H, W, 1), pix)
+
+
+@pytest.mark.parametrize("Cn", [1, 3])
+def test_almost_empty_pictures_with_runs_of_millions_of_zeros(ctx, Cn):
+    """A flat 2048x2048 picture with a handful of bright pixels: every plane is a few tokens whose runs count millions of
+    zeros and cross many segments (rle.h:79-101) — the decoder's chunk tables count such symbols in saturating 32 bits, its
+    walker takes the token that runs past a segment's end from the chunk it has in registers.  Bytes like the oracle's,
+    pictures back exactly, alone and as a batch of four (one family of recorded paths)."""
+    import torch
+
+    W = H = 2048
+    rng = np.random.default_rng(2048 + Cn)
+    pics = []
+    for k in range(4):
+        pix = np.full((H, W, Cn), 90 + 20 * k, dtype=np.uint8)
+        for _ in range(1 + 3 * k):
+            pix[int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(0, Cn))] = int(rng.integers(0, 256))
+        pics.append(pix)
+    want = [orc.encode(p)[0] for p in pics]
+    t = torch.from_numpy(np.stack(pics)).cuda()
+    streams, info = ctx.encode_device(t)
+    lens = ctx.stream_lengths(info)
+    for i, w in enumerate(want):
+        assert int(lens[i]) == len(w)
+        assert streams[i, : len(w)].cpu().numpy().tobytes() == w
+    out, infos = ctx.decode_device(streams, lens, W, H, Cn)
+    assert all(i.status == 0 and not i.truncated for i in infos)
+    assert torch.equal(out.view(4, H, W, Cn), t)
+    out1, infos1 = ctx.decode_device(streams[1:2].contiguous(), lens[1:2].contiguous(), W, H, Cn)
+    assert torch.equal(out1.view(1, H, W, Cn), t[1:2])
