@@ -1347,10 +1347,11 @@ __global__ __launch_bounds__(256) void k_clear_bitmaps(unsigned *bits, long BW, 
 // --------------------------------------------------------------- k_tokenize ---
 
 // decode.c:198-243: the order in which (channel, level, plane) segments follow one another.  seg(c, l, p) decodes
-// one and says whether decoding goes on; `level` and `missing` are kept as decode.c:197,203,219,236 keeps them.
+// one and says whether decoding goes on; `level` and `missing` (through one_less_missing(channel * 16 + level): the caller
+// says where its counters live) are kept as decode.c:197,203,219,236 keeps them.
 // Returns whether the walk stopped before the schedule's end (decode.c:199-200,204,221,238).
-template <class F>
-__device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&planes)[3], int pmax, int &level, int *missing, F &&seg)
+template <class F, class M>
+__device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&planes)[3], int pmax, int &level, M &&one_less_missing, F &&seg)
 {
 	const int levels = g.levels;
 	const int layers_max = 2 * (levels > pmax ? levels : pmax) - 1;
@@ -1358,7 +1359,7 @@ __device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&p
 	if (!stop && pmax == planes[0]) {     // decode.c:201-207
 		level = 0;
 		if (seg(0, 0, planes[0] - 1))
-			--missing[0];
+			one_less_missing(0);
 		else
 			stop = true;
 	}
@@ -1373,7 +1374,7 @@ __device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&p
 				continue;
 			level = level < l ? l : level;
 			if (seg(0, l, p))
-				--missing[l];
+				one_less_missing(l);
 			else
 				stop = true;
 		}
@@ -1388,7 +1389,7 @@ __device__ __forceinline__ bool walk_schedule(const UnpackGeom &g, const int (&p
 					continue;
 				level = level < l ? l : level;
 				if (seg(c, l, p))
-					--missing[c * 16 + l];
+					one_less_missing(c * 16 + l);
 				else
 					stop = true;
 			}
@@ -1777,7 +1778,12 @@ __global__ __launch_bounds__(64) void k_tokenize(UnpackGeom g, DWork w, const un
 		w.segres[(long)img * MAX_SEGS + seg_k] = r;
 		return;
 	}
-	stop = walk_schedule(g, planes, pmax, level, I.missing, segment);
+	// (decode.c:193-196's `missing` in the lanes of a register like the counters above: in memory every segment ended with a
+	// load, a decrement and a store of its entry)
+	int missing_v = wl < 48 && (wl >> 4) < g.C && (wl & 15) < g.levels ? planes[wl >> 4 < 3 ? wl >> 4 : 0] : 0;
+	stop = walk_schedule(g, planes, pmax, level, [&](int i) { missing_v = wl == i ? missing_v - 1 : missing_v; }, segment);
+	if (wl < 48 && (wl >> 4) < g.C && (wl & 15) < g.levels)
+		I.missing[wl] = missing_v;
 	bm.flush();
 	if (giveup) {   // nothing of this walk is used: no records for k_hopbits, the marker for the host
 		w.nhops[img] = 0;
@@ -1869,7 +1875,7 @@ __global__ __launch_bounds__(64) void k_segjoin(UnpackGeom g, DWork w, const uns
 	unsigned cnt = 0, hopped = 0, walked = 0;
 	int k = 0, level = -1;
 	bool good = K > 0 && g.levels_max >= g.levels;
-	const bool stop = walk_schedule(g, planes, pmax, level, I.missing, [&](int c, int l, int p) {
+	const bool stop = walk_schedule(g, planes, pmax, level, [&](int i) { --I.missing[i]; }, [&](int c, int l, int p) {
 		const int num = g.pixels[l + 1] - g.pixels[l];
 		const int n1 = p < 0 ? num : nonsig[c * 16 + l];
 		good = good && k < K;
